@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py - alignment columns/s of the MI355X forward log-likelihood path (BASELINE.json metric).
+
+A "step" is one evaluation of the summed log-likelihood (one pass of the hot path) over this
+job's synthetic alignment chunks, which are resident in HBM before the timed region starts; the
+per-step host input is only (pi, T, E) (a few KB), exactly what Forwarder.forward receives.
+
+  N=1  : BASELINE config[1] - isolation model, 20 states, 1 x 100 Mbp synthetic pairwise alignment
+  N>1  : BASELINE config[3] sliced per GPU - 32 x 10 Mbp chunks per rank (256 chunks at N=8),
+         chunks sharded statically, one RCCL all-reduce(sum) of the partial log-likelihoods per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` and, at N=1,
+`cpu_baseline`.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 fp64 FMA lanes x 2 x 2.4 GHz
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--states", type=int, default=20)
+    ap.add_argument("--columns", type=int, default=0, help="override columns per chunk")
+    ap.add_argument("--chunks", type=int, default=0, help="override chunks per rank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-columns", type=int, default=4_000_000, help="columns per CPU thread")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    if world != n_gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, n_gpus))
+
+    import torch
+    import torch.distributed as dist
+    from imcoalhmm_amd import Forwarder, _capi, synth
+    from imcoalhmm_amd.dist import DistributedLikelihood, shard_indices
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = _capi.lib()                       # raises if the HIP library is missing (no fallback)
+    _capi.check(lib.imc_set_device(local_rank))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload -------------------------------------------------------------------------------
+    d = np.load(os.path.join(REPO, "tests", "golden", "hmm_params.npz"))
+    key = "iso%d_t0" % args.states
+    if key + "_pi" not in d.files:
+        raise SystemExit("no (pi,T,E) fixture for %d states" % args.states)
+    pi, T, E = d[key + "_pi"], d[key + "_T"], d[key + "_E"]
+    n_states = pi.shape[0]
+    if world == 1:
+        chunks_per_rank = args.chunks or 1
+        cols = args.columns or 100_000_000
+        workload = "isolation-model %d states, %d x %d-column synthetic pairwise alignment (BASELINE config[1])" % (
+            n_states, chunks_per_rank, cols)
+        seeds = [20240001 + k for k in range(chunks_per_rank)]
+    else:
+        chunks_per_rank = args.chunks or 32
+        cols = args.columns or 10_000_000
+        workload = "isolation-model %d states, %d x %d-column synthetic chunks sharded over %d GPUs (BASELINE config[3] slice)" % (
+            n_states, chunks_per_rank * world, cols, world)
+        seeds = [20240100 + i for i in shard_indices(chunks_per_rank * world, rank, world)]
+
+    t0 = time.time()
+    forwarders = []
+    first_chunk = None
+    for sd in seeds:
+        # generated in 1e7-column pieces to bound host memory
+        parts = [synth.sample_alignment(pi, T, E, min(10_000_000, cols - off), seed=sd * 1000 + k)
+                 for k, off in enumerate(range(0, cols, 10_000_000))]
+        obs = parts[0] if len(parts) == 1 else np.concatenate(parts)
+        if first_chunk is None:
+            first_chunk = obs
+        forwarders.append(Forwarder.from_array(obs, 3))
+    t_setup = time.time() - t0
+    local_cols = sum(len(f) for f in forwarders)
+
+    class FixedModel(object):   # the model layer stays CPU-side (north_star); the bench holds theta fixed
+        def valid_parameters(self, p):
+            return True
+
+        def build_hidden_markov_model(self, p):
+            return pi, T, E
+
+    ll = DistributedLikelihood(FixedModel(), forwarders, device=dev)
+
+    def step():
+        return ll.forward_params(pi, T, E)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        value = step()
+    lib.imc_profile_enable(1)
+    ms_p, ms_s = ctypes.c_double(), ctypes.c_double()
+    n_p, n_s = ctypes.c_uint64(), ctypes.c_uint64()
+    lib.imc_profile_read(ctypes.byref(ms_p), ctypes.byref(ms_s), ctypes.byref(n_p), ctypes.byref(n_s))  # reset
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        value = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.imc_profile_read(ctypes.byref(ms_p), ctypes.byref(ms_s), ctypes.byref(n_p), ctypes.byref(n_s))
+    lib.imc_profile_enable(0)
+    segs, vecs, seglen, vcols = (ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64())
+    lib.imc_last_plan(ctypes.byref(segs), ctypes.byref(vecs), ctypes.byref(seglen), ctypes.byref(vcols))
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([float(local_cols)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_cols = float(tot.item())
+    else:
+        total_cols = float(local_cols)
+
+    if rank == 0:
+        cols_per_s = total_cols * args.steps / elapsed
+        k_ms = ms_p.value / max(n_p.value, 1)            # average propagate-kernel duration (HIP events)
+        k_s = k_ms * 1e-3
+        alg_bytes = float(local_cols) * 1.0               # 1 B of observation stream per column
+        alg_flops = float(local_cols) * (2 * n_states * n_states + 3 * n_states)
+        exe_flops = float(vcols.value) * (2 * n_states * n_states + 3 * n_states)
+        achieved_gbs = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
+        out = {
+            "metric": "alignment columns/sec (forward pass), %d-state isolation HMM" % n_states,
+            "value": cols_per_s,
+            "unit": "columns/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": workload, "states": n_states, "chunks_per_gpu": chunks_per_rank,
+                       "columns_per_chunk": cols, "evals_per_s": args.steps / elapsed,
+                       "segments": segs.value, "vectors": vecs.value, "segment_len": seglen.value,
+                       "setup_s": t_setup, "loglik": value},
+            "roofline": {
+                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_propagate", "kernel_ms": k_ms, "stitch_ms": ms_s.value / max(n_s.value, 1),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "north_star names the HBM roof, but with 1 B/column the path is fp64-VALU/latency bound; "
+                        "see fp64_valu",
+                "fp64_valu": {
+                    "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                    "algorithmic_tflops": alg_flops / k_s / 1e12 if k_s > 0 else 0.0,
+                    "executed_tflops": exe_flops / k_s / 1e12 if k_s > 0 else 0.0,
+                    "frac_algorithmic": alg_flops / k_s / 1e12 / FP64_VALU_PEAK_TFLOPS if k_s > 0 else 0.0,
+                    "frac_executed": exe_flops / k_s / 1e12 / FP64_VALU_PEAK_TFLOPS if k_s > 0 else 0.0,
+                },
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pi, T, E, first_chunk, args.cpu_sample_columns)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pi, T, E, obs, cols_per_thread):
+    """The CPU oracle (a port: ziphmm itself is not installable offline) timed on this host's cores,
+    on a bounded sample of the same alignment: one `cols_per_thread` slice per thread, each slice
+    evaluated as its own chunk (timing only)."""
+    from oracle import oracle_lib
+    oracle_lib.build()
+    cores = min(os.cpu_count() or 1, oracle_lib.max_threads(), 64)
+    n = min(cols_per_thread, obs.size // cores if cores else obs.size)
+    slices = [obs[k * n:(k + 1) * n] for k in range(cores)]
+    zips = [oracle_lib.Zip(s, 3) for s in slices]                 # one-time preprocessing, not timed (hmm.py:16)
+    t0 = time.perf_counter()
+    oracle_lib.forward_chunks_mt(pi, T, E, slices, threads=cores, zips=zips)
+    t_zip = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oracle_lib.forward_chunks_mt(pi, T, E, slices, threads=cores)
+    t_plain = time.perf_counter() - t0
+    total = float(n * cores)
+    best = min(t_zip, t_plain)
+    return {"value": total / best, "unit": "columns/s", "cores": cores, "kind": "port",
+            "sample": "%d threads x %d columns of the same synthetic alignment, each slice its own chunk; "
+                      "zipHMM-style compressed forward %.3g col/s (compression ratio %.1fx), textbook scaled "
+                      "forward %.3g col/s; CPU restatement of the ziphmm forward, ziphmm itself is not "
+                      "installable offline" % (cores, n, total / t_zip, n / max(zips[0].length, 1), total / t_plain)}
+
+
+if __name__ == "__main__":
+    main()

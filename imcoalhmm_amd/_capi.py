@@ -1,0 +1,109 @@
+"""ctypes binding of libimcoal_fwd.so (include/imcoal_fwd.h).
+
+There is no CPU fallback: if the HIP library is missing or no gfx950 device is usable, every
+compute call raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported
+from here.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libimcoal_fwd.so")
+
+IMC_OK = 0
+IMC_ERR_ARG = -1
+IMC_ERR_SYMBOL = -2
+IMC_ERR_HIP = -3
+IMC_ERR_OOM = -4
+IMC_ERR_IO = -5
+IMC_ERR_NODEVICE = -6
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+
+# every symbol include/imcoal_fwd.h declares: (name, restype, argtypes)
+SIGNATURES = [
+    ("imc_version", ctypes.c_char_p, []),
+    ("imc_last_error", ctypes.c_char_p, []),
+    ("imc_device_count", ctypes.c_int, []),
+    ("imc_set_device", ctypes.c_int, [ctypes.c_int]),
+    ("imc_obs_create", ctypes.c_int, [_u8p, ctypes.c_size_t, ctypes.c_int, _vpp]),
+    ("imc_obs_create_i32", ctypes.c_int, [_i32p, ctypes.c_size_t, ctypes.c_int, _vpp]),
+    ("imc_obs_create_from_text", ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, _vpp]),
+    ("imc_obs_length", ctypes.c_size_t, [ctypes.c_void_p]),
+    ("imc_obs_nsym", ctypes.c_int, [ctypes.c_void_p]),
+    ("imc_obs_free", ctypes.c_int, [ctypes.c_void_p]),
+    ("imc_forward", ctypes.c_int, [_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
+    ("imc_forward_batch", ctypes.c_int,
+     [_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
+    ("imc_forward_batch_per_chunk", ctypes.c_int,
+     [_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
+    ("imc_forward_batch_device", ctypes.c_int,
+     [_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, ctypes.c_void_p,
+      ctypes.c_void_p]),
+    ("imc_set_segment_length", ctypes.c_int, [ctypes.c_size_t]),
+    ("imc_profile_enable", ctypes.c_int, [ctypes.c_int]),
+    ("imc_profile_read", ctypes.c_int, [_dp, _dp, _u64p, _u64p]),
+    ("imc_last_plan", ctypes.c_int, [_u64p, _u64p, _u64p, _u64p]),
+]
+
+_lib = None
+
+
+class ImcError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libimcoal_fwd error %d: %s" % (code, message))
+        self.code = code
+
+
+def lib():
+    """Load the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s is missing - build it with `python -m imcoalhmm_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SIGNATURES:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc == IMC_OK:
+        return
+    msg = lib().imc_last_error().decode("utf-8", "replace")
+    if rc in (IMC_ERR_ARG, IMC_ERR_SYMBOL):
+        raise ValueError("libimcoal_fwd: " + msg)
+    if rc == IMC_ERR_IO:
+        raise IOError("libimcoal_fwd: " + msg)
+    if rc == IMC_ERR_OOM:
+        raise MemoryError("libimcoal_fwd: " + msg)
+    raise ImcError(rc, msg)
+
+
+def as_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError("expected shape %r, got %r" % (shape, a.shape))
+    return a
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp)
+
+
+def handle_array(handles):
+    arr = (ctypes.c_void_p * max(len(handles), 1))()
+    for i, h in enumerate(handles):
+        arr[i] = h
+    return arr

@@ -1,0 +1,83 @@
+"""Multi-GPU sharding of the likelihood: one process per GPU, chunks partitioned statically,
+one RCCL sum of the per-rank partial log-likelihoods (backend "nccl" is RCCL on ROCm).
+
+The path shards exactly where the reference's ``Likelihood.__call__`` sums over forwarders
+(src/IMCoalHMM/likelihood.py:33): chunks are independent, every rank holds the (tiny) parameter
+set, and the only exchange is ``all_reduce(sum)`` of B doubles per evaluation batch.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _capi, hmm
+
+
+def shard_indices(n_chunks, rank, world_size):
+    """Static round-robin partition: chunk i -> rank i mod world_size."""
+    return list(range(rank, n_chunks, world_size))
+
+
+class DistributedLikelihood(object):
+    """``Likelihood`` whose forwarders are this rank's shard; every rank gets the global value.
+
+    ``local_eval(pis, Ts, Es) -> tensor[B]`` may be injected (CPU/gloo tests); by default the HIP
+    library writes the rank's partial sums straight into a device tensor on torch's current stream
+    and RCCL reduces it in place.
+    """
+
+    def __init__(self, model, local_forwarders, group=None, device=None, local_eval=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.model = model
+        if hasattr(local_forwarders, '__iter__'):
+            self.forwarders = list(local_forwarders)
+        else:
+            self.forwarders = [local_forwarders]
+        self.group = group
+        self.device = device
+        self._local_eval = local_eval or self._hip_eval
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def _hip_eval(self, pis, Ts, Es):
+        torch = self._torch
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        B, n = pis.shape
+        partial = torch.empty(B, dtype=torch.float64, device=dev)
+        handles = [f.handle for f in self.forwarders]
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _capi.check(_capi.lib().imc_forward_batch_device(
+            _capi.handle_array(handles), len(handles), B, n, Es.shape[2],
+            _capi.dptr(pis), _capi.dptr(Ts), _capi.dptr(Es),
+            ctypes.c_void_p(partial.data_ptr()), ctypes.c_void_p(stream)))
+        return partial
+
+    def forward_params_batch(self, pis, Ts, Es):
+        """Global log-likelihoods (float64[B]) for B parameter sets; collective over the group."""
+        pis, Ts, Es = hmm._batch_params(pis, Ts, Es)
+        partial = self._local_eval(pis, Ts, Es)
+        if self.world_size > 1:
+            self._dist.all_reduce(partial, op=self._dist.ReduceOp.SUM, group=self.group)
+        return partial.detach().cpu().numpy()
+
+    def forward_params(self, pi, T, E):
+        pi, T, E = hmm._params(pi, T, E)
+        return float(self.forward_params_batch(pi[None], T[None], E[None])[0])
+
+    def __call__(self, *parameters):
+        if not self.model.valid_parameters(*parameters):
+            return -float('inf')
+        return self.forward_params(*self.model.build_hidden_markov_model(*parameters))
+
+    def batch(self, thetas):
+        thetas = [np.asarray(t, dtype=np.float64) for t in thetas]
+        out = np.full(len(thetas), -np.inf, dtype=np.float64)
+        valid = [k for k, t in enumerate(thetas) if self.model.valid_parameters(t)]
+        if valid:
+            hmms = [self.model.build_hidden_markov_model(thetas[k]) for k in valid]
+            vals = self.forward_params_batch(
+                np.stack([np.asarray(h[0], dtype=np.float64).reshape(-1) for h in hmms]),
+                np.stack([np.asarray(h[1], dtype=np.float64) for h in hmms]),
+                np.stack([np.asarray(h[2], dtype=np.float64) for h in hmms]))
+            out[valid] = vals
+        return out

@@ -1,0 +1,123 @@
+"""Drop-in for IMCoalHMM.hmm.Forwarder (reference: src/IMCoalHMM/hmm.py:10-21) on MI355X.
+
+Same constructor and ``forward`` signature as the reference class; the observation sequence is
+parsed by the C library, copied to HBM once and stays resident (the role that
+``ziphmm.preprocess_raw_observations`` plays at hmm.py:16), and ``forward`` runs the HIP
+parallel-in-time forward (the role of ``ziphmm.zip_forward`` at hmm.py:20-21).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _capi
+
+
+def _params(init_probs, trans_probs, emission_probs):
+    pi = _capi.as_f64(np.asarray(init_probs)).reshape(-1)
+    T = _capi.as_f64(np.asarray(trans_probs))
+    E = _capi.as_f64(np.asarray(emission_probs))
+    n = pi.shape[0]
+    if T.shape != (n, n):
+        raise ValueError("trans_probs must be (%d,%d), got %r" % (n, n, T.shape))
+    if E.ndim != 2 or E.shape[0] != n:
+        raise ValueError("emission_probs must be (%d,NSYM), got %r" % (n, E.shape))
+    return pi, T, E
+
+
+def _batch_params(pis, Ts, Es):
+    pis = _capi.as_f64(np.asarray(pis))
+    Ts = _capi.as_f64(np.asarray(Ts))
+    Es = _capi.as_f64(np.asarray(Es))
+    if pis.ndim != 2 or Ts.ndim != 3 or Es.ndim != 3:
+        raise ValueError("batched parameters must be pis[B,N], Ts[B,N,N], Es[B,N,S]")
+    B, n = pis.shape
+    if Ts.shape != (B, n, n) or Es.shape[:2] != (B, n):
+        raise ValueError("inconsistent batched parameter shapes %r %r %r" % (pis.shape, Ts.shape, Es.shape))
+    return pis, Ts, Es
+
+
+def forward_chunks(handles, pi, T, E):
+    """Sum of chunk log-likelihoods for one parameter set (likelihood.py:33)."""
+    pi, T, E = _params(pi, T, E)
+    out = ctypes.c_double(0.0)
+    _capi.check(_capi.lib().imc_forward(_capi.handle_array(handles), len(handles), pi.shape[0], E.shape[1],
+                                        _capi.dptr(pi), _capi.dptr(T), _capi.dptr(E), ctypes.byref(out)))
+    return out.value
+
+
+def forward_chunks_batch(handles, pis, Ts, Es, per_chunk=False):
+    pis, Ts, Es = _batch_params(pis, Ts, Es)
+    B, n = pis.shape
+    S = Es.shape[2]
+    L = _capi.lib()
+    if per_chunk:
+        out = np.zeros((B, len(handles)), dtype=np.float64)
+        _capi.check(L.imc_forward_batch_per_chunk(_capi.handle_array(handles), len(handles), B, n, S,
+                                                  _capi.dptr(pis), _capi.dptr(Ts), _capi.dptr(Es), _capi.dptr(out)))
+    else:
+        out = np.zeros(B, dtype=np.float64)
+        _capi.check(L.imc_forward_batch(_capi.handle_array(handles), len(handles), B, n, S,
+                                        _capi.dptr(pis), _capi.dptr(Ts), _capi.dptr(Es), _capi.dptr(out)))
+    return out
+
+
+class Forwarder(object):
+    """``Forwarder(input_filename, NSYM)`` - same surface as the reference class (hmm.py:10-21).
+
+    ``input_filename`` is a text file of whitespace-separated symbols as written by
+    scripts/prepare-alignments.py.  Extra, additive constructors: ``Forwarder.from_array``.
+    """
+
+    def __init__(self, input_filename, NSYM):
+        self.NSYM = int(NSYM)
+        self._h = None
+        h = ctypes.c_void_p()
+        _capi.check(_capi.lib().imc_obs_create_from_text(os.fsencode(input_filename), self.NSYM, ctypes.byref(h)))
+        self._h = h.value
+        self._pid = os.getpid()
+
+    @classmethod
+    def from_array(cls, obs, NSYM):
+        """Build from an in-memory symbol array (uint8 or any integer dtype)."""
+        self = cls.__new__(cls)
+        self.NSYM = int(NSYM)
+        self._h = None
+        h = ctypes.c_void_p()
+        obs = np.asarray(obs)
+        L = _capi.lib()
+        if obs.dtype == np.uint8:
+            a = np.ascontiguousarray(obs)
+            _capi.check(L.imc_obs_create(a.ctypes.data_as(_capi._u8p), a.size, self.NSYM, ctypes.byref(h)))
+        else:
+            a = np.ascontiguousarray(obs, dtype=np.int32)     # the reference's own dtype (hmm.py:14)
+            _capi.check(L.imc_obs_create_i32(a.ctypes.data_as(_capi._i32p), a.size, self.NSYM, ctypes.byref(h)))
+        self._h = h.value
+        self._pid = os.getpid()
+        return self
+
+    def __len__(self):
+        return int(_capi.lib().imc_obs_length(self._h))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def forward(self, init_probs, trans_probs, emission_probs):
+        """log P(observations | pi, T, E) - reference: hmm.py:19-21."""
+        return forward_chunks([self._h], init_probs, trans_probs, emission_probs)
+
+    def forward_batch(self, pis, Ts, Es):
+        """B parameter sets in one device pass: returns float64[B]."""
+        return forward_chunks_batch([self._h], pis, Ts, Es)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._pid == os.getpid():
+            try:
+                _capi.lib().imc_obs_free(self._h)
+            except Exception:
+                pass
+        self._h = None
+
+    def __del__(self):
+        self.close()

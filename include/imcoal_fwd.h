@@ -1,0 +1,106 @@
+/*
+ * imcoal_fwd.h - C ABI of libimcoal_fwd.so, the MI355X (gfx950) HMM forward log-likelihood engine
+ * that replaces the `ziphmm` calls behind IMCoalHMM's Forwarder / Likelihood.
+ *
+ * The reference has no FFI of its own for this path: it is pure Python calling the third-party
+ * `ziphmm` extension module.  Each entry point below names the reference call it replaces
+ * (paths relative to /root/reference).  INTEGRATION.md shows the ctypes stub a maintainer would
+ * put in src/IMCoalHMM/hmm.py.
+ *
+ * Conventions (identical to what the reference's model layer produces, model.py:44-49):
+ *   all matrices row-major float64;  pi[N];  T[i*N+j] = P(next=j|cur=i) (transitions.py:241-248);
+ *   E[j*S+s] = P(symbol s|state j) (emissions.py:89-100);  symbols are integers in [0,S).
+ *   Every chunk (alignment file) restarts from pi and chunk log-likelihoods are summed
+ *   left-to-right starting from 0.0 (likelihood.py:33).
+ *   A zero-probability sequence yields -inf (not an error); NaN in -> NaN out.
+ *
+ * Ownership: input buffers are borrowed for the duration of the call only.  Observations are
+ * copied to device memory at imc_obs_create* and owned by the library until imc_obs_free.
+ * All functions return IMC_OK (0) or a negative error code; imc_last_error() gives the message
+ * (thread-local).  There is NO CPU fallback: without a HIP device every compute entry point
+ * fails with IMC_ERR_NODEVICE.
+ *
+ * Threads / processes: no HIP call is made before the first compute/create call, and the device
+ * context is re-created lazily per PID, so Forwarders may be built inside multiprocessing
+ * children as mcmc.py:112-121 does.  Calls are serialised internally by one mutex.
+ */
+#ifndef IMCOAL_FWD_H
+#define IMCOAL_FWD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    IMC_OK = 0,
+    IMC_ERR_ARG = -1,      /* bad shape / null pointer / unsupported size */
+    IMC_ERR_SYMBOL = -2,   /* observation symbol >= nsym */
+    IMC_ERR_HIP = -3,      /* HIP runtime error */
+    IMC_ERR_OOM = -4,      /* host or device allocation failed */
+    IMC_ERR_IO = -5,       /* cannot read / parse the observation file */
+    IMC_ERR_NODEVICE = -6  /* no usable gfx950 device */
+};
+
+typedef struct imc_obs imc_obs; /* one alignment file ("chunk"), resident in HBM */
+
+/* Library / device management ------------------------------------------------------------ */
+const char *imc_version(void);
+const char *imc_last_error(void);
+int imc_device_count(void);          /* number of HIP devices, 0 if none (never an error) */
+int imc_set_device(int device);      /* device used by subsequent calls of this process (default:
+                                        the calling thread's current HIP device) */
+
+/* Observations: replaces Forwarder.__init__, src/IMCoalHMM/hmm.py:12-16
+ * (read text -> np.int32[L] -> ziphmm.preprocess_raw_observations(obs, NSYM)). -------------- */
+int imc_obs_create(const uint8_t *sym, size_t L, int nsym, imc_obs **out);
+int imc_obs_create_i32(const int32_t *sym, size_t L, int nsym, imc_obs **out);   /* hmm.py:14 dtype */
+/* File of whitespace-separated decimal tokens, the format written by
+ * scripts/prepare-alignments.py:92-105 and read at hmm.py:13-14. */
+int imc_obs_create_from_text(const char *path, int nsym, imc_obs **out);
+size_t imc_obs_length(const imc_obs *obs);
+int imc_obs_nsym(const imc_obs *obs);
+int imc_obs_free(imc_obs *obs);
+
+/* Forward log-likelihood: replaces Forwarder.forward -> ziphmm.zip_forward,
+ * src/IMCoalHMM/hmm.py:19-21, and the sum over forwarders at likelihood.py:33.
+ * out_loglik[0] = sum_f log P(chunk_f | pi,T,E). */
+int imc_forward(const imc_obs *const *chunks, int n_chunks, int N, int S,
+                const double *pi, const double *T, const double *E, double *out_loglik);
+
+/* B parameter sets against the same chunks in one pass (the evaluation streams of
+ * genetic_algorithm.py:818-831, mcmc.py:165-174).  pis[B][N], Ts[B][N][N], Es[B][N][S];
+ * out_logliks[B] (summed over chunks). */
+int imc_forward_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S,
+                      const double *pis, const double *Ts, const double *Es, double *out_logliks);
+
+/* Same, but also returns every chunk's own value: out_per_chunk[B][n_chunks]. */
+int imc_forward_batch_per_chunk(const imc_obs *const *chunks, int n_chunks, int B, int N, int S,
+                                const double *pis, const double *Ts, const double *Es,
+                                double *out_per_chunk);
+
+/* Multi-GPU building block: partial sums stay on the device.  d_out_partial is a DEVICE pointer
+ * to B doubles, written on `hip_stream` (a hipStream_t, may be NULL for the library's stream);
+ * the call returns after enqueueing.  The caller then all-reduces d_out_partial over ranks
+ * (RCCL sum).  Parameters are still host pointers. */
+int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, int N, int S,
+                             const double *pis, const double *Ts, const double *Es,
+                             double *d_out_partial, void *hip_stream);
+
+/* Tuning / measurement ------------------------------------------------------------------ */
+/* Target segment length in columns for the parallel-in-time split (0 = automatic). */
+int imc_set_segment_length(size_t columns);
+/* Kernel timing with HIP events on the launch stream.  After imc_profile_enable(1) every
+ * propagate/stitch launch is bracketed by events; imc_profile_read synchronises, returns the
+ * accumulated device milliseconds and launch counts since the last reset, and resets. */
+int imc_profile_enable(int on);
+int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propagate, uint64_t *n_stitch);
+/* Description of the last launch plan (segments, vectors, segment length, executed vector-columns). */
+int imc_last_plan(uint64_t *n_segments, uint64_t *n_vectors, uint64_t *segment_len, uint64_t *vector_columns);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMCOAL_FWD_H */

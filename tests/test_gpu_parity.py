@@ -1,0 +1,203 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle.
+
+Tolerance: north_star asks for <= 1e-9 relative on the summed log-likelihood; the engine only
+re-associates fp64 arithmetic (exact power-of-two rescaling), so the tests hold it to 1e-11.
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from imcoalhmm_amd import Forwarder, Likelihood, _capi, synth
+from imcoalhmm_amd.hmm import forward_chunks, forward_chunks_batch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _lib_loaded():
+    L = _capi.lib()
+    assert L.imc_device_count() >= 1, "gpu tests need a device"
+    yield
+    L.imc_set_segment_length(0)
+
+
+def set_seg(n):
+    _capi.check(_capi.lib().imc_set_segment_length(n))
+
+
+def test_config1_example_data_golden(hmm_params, example_pairs, golden_loglik):
+    """BASELINE config 1 (10 states, examples/example_data.fa) and the other golden cells, N<=20."""
+    fw = {k: Forwarder.from_array(v, 3) for k, v in example_pairs.items()}
+    for key, rec in golden_loglik.items():
+        pname, mkey = key.split("|")
+        if mkey.startswith("im150"):
+            continue
+        pi, T, E = hmm_params(mkey)
+        got = fw[pname].forward(pi, T, E)
+        assert rel_err(got, rec["loglik"]) < TOL, (key, got, rec["loglik"])
+
+
+@pytest.mark.parametrize("seg", [0, 16, 48, 1000, 4096])
+def test_segmentation_invariance(hmm_params, example_pairs, golden_loglik, seg):
+    """The parallel-in-time split must not change the answer (exact re-association)."""
+    try:
+        set_seg(seg)
+        f = Forwarder.from_array(example_pairs["hg18__pantro2"], 3)
+        for mkey in ("iso10_t0", "iso20_t0", "im20_t0"):
+            got = f.forward(*hmm_params(mkey))
+            assert rel_err(got, golden_loglik["hg18__pantro2|" + mkey]["loglik"]) < TOL, (mkey, seg)
+    finally:
+        set_seg(0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 10, 12, 13, 16, 17, 20, 21, 24, 25, 28, 29, 32, 33, 40, 41, 48, 50, 56, 57, 64])
+@pytest.mark.parametrize("nsym", [3])
+def test_random_hmms_all_kernel_shapes(oracle, n, nsym):
+    """Every (R,G) instantiation, padded and unpadded N, with stitching forced (seg=160)."""
+    pi, T, E = synth.random_hmm(n, nsym, seed=100 + n, stay=0.98)
+    rng = np.random.default_rng(n)
+    chunks = [rng.integers(0, nsym, size=L).astype(np.uint8) for L in (1, 15, 16, 17, 333, 1500)]
+    fw = [Forwarder.from_array(c, nsym) for c in chunks]
+    try:
+        set_seg(160)
+        got = forward_chunks_batch([f.handle for f in fw], pi[None], T[None], E[None], per_chunk=True)[0]
+    finally:
+        set_seg(0)
+    for c, g in zip(chunks, got):
+        want = oracle.forward_scaled(pi, T, E, c)
+        assert rel_err(g, want) < TOL, (n, c.size, g, want)
+
+
+@pytest.mark.parametrize("nsym", [1, 2, 4, 5, 16, 65, 256])
+def test_alphabet_sizes(oracle, nsym):
+    pi, T, E = synth.random_hmm(9, nsym, seed=nsym, stay=0.9)
+    obs = np.random.default_rng(nsym).integers(0, nsym, size=3000).astype(np.uint8)
+    got = Forwarder.from_array(obs, nsym).forward(pi, T, E)
+    assert rel_err(got, oracle.forward_scaled(pi, T, E, obs)) < TOL
+
+
+def test_ragged_and_empty_chunks_sum(oracle, hmm_params):
+    """likelihood.py:33 semantics: each chunk restarts from pi, values summed left to right."""
+    pi, T, E = hmm_params("iso20_t0")
+    lens = [0, 1, 2, 15, 16, 17, 31, 32, 33, 1000, 4097, 65255, 0, 20000]
+    chunks = [synth.sample_alignment(pi, T, E, n, seed=500 + k) for k, n in enumerate(lens)]
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    want = [oracle.forward_scaled(pi, T, E, c) for c in chunks]
+    for seg in (0, 64, 1024):
+        try:
+            set_seg(seg)
+            per = forward_chunks_batch([f.handle for f in fw], pi[None], T[None], E[None], per_chunk=True)[0]
+            tot = forward_chunks([f.handle for f in fw], pi, T, E)
+        finally:
+            set_seg(0)
+        for g, w, n in zip(per, want, lens):
+            assert (g == 0.0 and w == 0.0) or rel_err(g, w) < TOL, (seg, n, g, w)
+        s = 0.0
+        for g in per:
+            s += g
+        assert tot == s                       # same left-to-right sum as Python's sum()
+        assert rel_err(tot, sum(want)) < TOL
+    # Likelihood over the same forwarders
+    class M(object):
+        def valid_parameters(self, p):
+            return all(p > 0)
+
+        def build_hidden_markov_model(self, p):
+            return pi, T, E
+    ll = Likelihood(M(), fw)
+    assert ll(np.array([1.0])) == tot
+    assert ll(np.array([-1.0])) == -math.inf
+
+
+def test_batch_of_parameter_sets(oracle, hmm_params):
+    keys = ["iso20_t0", "iso20_t1", "iso20_t2", "iso20_t3", "im20_t0", "im20_t1"]
+    ps = [hmm_params(k) for k in keys]
+    pis = np.stack([p[0] for p in ps]); Ts = np.stack([p[1] for p in ps]); Es = np.stack([p[2] for p in ps])
+    chunks = [synth.sample_alignment(*ps[0], 30_000, seed=900 + k) for k in range(5)]
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    try:
+        set_seg(2048)
+        got = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es)
+    finally:
+        set_seg(0)
+    for b, k in enumerate(keys):
+        want = sum(oracle.forward_scaled(*ps[b], c) for c in chunks)
+        assert rel_err(got[b], want) < TOL, k
+        assert rel_err(forward_chunks([f.handle for f in fw], *ps[b]), want) < TOL
+
+
+def test_text_file_constructor(oracle, hmm_params, example_pairs, tmp_path):
+    """Forwarder(input_filename, NSYM) on the reference's own text format (hmm.py:12-14)."""
+    obs = example_pairs["hg18__bonobo"][:20000]
+    p = tmp_path / "pair.ziphmm"
+    p.write_text(" ".join(str(int(s)) for s in obs) + " ")     # prepare-alignments.py:99-105 writes "%d "
+    f = Forwarder(str(p), NSYM=3)
+    assert len(f) == obs.size
+    pi, T, E = hmm_params("iso10_t0")
+    assert rel_err(f.forward(pi, T, E), oracle.forward_scaled(pi, T, E, obs)) < TOL
+    p2 = tmp_path / "nl.txt"
+    p2.write_text("\n".join(str(int(s)) for s in obs[:100]))   # newline separated, no trailing space
+    assert len(Forwarder(str(p2), 3)) == 100
+
+
+def test_impossible_sequence_and_nan(hmm_params):
+    pi = np.array([0.5, 0.5]); T = np.array([[0.9, 0.1], [0.1, 0.9]])
+    E = np.array([[1.0, 0.0], [1.0, 0.0]])
+    obs = np.zeros(500, dtype=np.uint8); obs[250] = 1
+    try:
+        for seg in (0, 64):
+            set_seg(seg)
+            assert Forwarder.from_array(obs, 2).forward(pi, T, E) == -math.inf
+            Tn = T.copy(); Tn[0, 0] = np.nan
+            assert math.isnan(Forwarder.from_array(obs, 2).forward(pi, Tn, E))
+    finally:
+        set_seg(0)
+
+
+def test_underflow_guard_long_rare_symbol_runs(oracle):
+    """Long runs of a very unlikely symbol: the power-of-two rescale must keep everything finite."""
+    n = 20
+    pi, T, E = synth.random_hmm(n, 3, seed=77, stay=0.9995)
+    E[:, 1] = 1e-12
+    E[:, 0] = 1.0 - 1e-12 - E[:, 2]
+    obs = np.zeros(40_000, dtype=np.uint8)
+    obs[1000:9000] = 1
+    got = Forwarder.from_array(obs, 3).forward(pi, T, E)
+    want = oracle.forward_scaled(pi, T, E, obs)
+    assert math.isfinite(got) and rel_err(got, want) < TOL
+
+
+def test_closed_form_at_full_size(hmm_params):
+    """Size-independent property at BASELINE's 1e8-column scale is in test_gpu_fullsize.py;
+    here a 4e6-column closed form (rank-one T) to keep this module fast."""
+    n, nsym = 20, 3
+    rng = np.random.default_rng(3)
+    q = rng.random(n); q /= q.sum()
+    T = np.tile(q, (n, 1))
+    E = rng.random((n, nsym)); E /= E.sum(axis=1, keepdims=True)
+    pi = rng.random(n); pi /= pi.sum()
+    obs = rng.integers(0, nsym, size=4_000_000).astype(np.uint8)
+    per_sym = np.log(q @ E)
+    cnt = np.bincount(obs[1:], minlength=nsym)
+    want = math.log(pi @ E[:, obs[0]]) + float(cnt @ per_sym)
+    got = Forwarder.from_array(obs, nsym).forward(pi, T, E)
+    assert rel_err(got, want) < 1e-10
+
+
+def test_bad_arguments_raise(hmm_params):
+    pi, T, E = hmm_params("iso10_t0")
+    f = Forwarder.from_array(np.zeros(100, dtype=np.uint8), 3)
+    with pytest.raises(ValueError):
+        f.forward(pi, T[:5], E)
+    with pytest.raises(ValueError):
+        f.forward(pi, T, E[:, :2])           # chunk alphabet (3) larger than S=2
+    with pytest.raises(ValueError):
+        Forwarder.from_array(np.array([0, 5], dtype=np.uint8), 3)
+    big = synth.random_hmm(65, 3, 1)
+    with pytest.raises(ValueError):
+        f.forward(*big)                      # N beyond the largest built kernel is refused loudly
