@@ -84,6 +84,13 @@ template <int R, int NP, bool PRED, bool SUM>
 __device__ __forceinline__ void column_step(double (&xo)[R], const double (&Tb)[R][NP], double *xw, int own,
                                             const double *Et, int sym, bool act, bool skipT, double &s)
 {
+    // emission factors first: their LDS latency hides under the FMA chains (Et is read-only)
+    double ev[R];
+    {
+        const double *e = Et + sym * NP + own;
+#pragma unroll
+        for (int k = 0; k < R; ++k) ev[k] = e[k];
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k) xw[own + k] = xo[k];
     wave_fence();
@@ -109,14 +116,13 @@ __device__ __forceinline__ void column_step(double (&xo)[R], const double (&Tb)[
         if (SUM) s += t;
     }
     wave_fence();
-    const double *e = Et + sym * NP + own;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         if (PRED) {
-            const double y = (skipT ? xo[k] : acc[k]) * e[k];
+            const double y = (skipT ? xo[k] : acc[k]) * ev[k];
             xo[k] = act ? y : xo[k];
         } else {
-            xo[k] = acc[k] * e[k];
+            xo[k] = acc[k] * ev[k];
         }
     }
 }
