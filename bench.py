@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--columns", type=int, default=0, help="override columns per chunk")
     ap.add_argument("--chunks", type=int, default=0, help="override chunks per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-compress", action="store_true",
+                    help="per-column kernel only (skip the pair-compressed token path)")
     ap.add_argument("--cpu-sample-columns", type=int, default=4_000_000, help="columns per CPU thread")
     args = ap.parse_args()
 
@@ -56,6 +58,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     lib = _capi.lib()                       # raises if the HIP library is missing (no fallback)
     _capi.check(lib.imc_set_device(local_rank))
+    _capi.check(lib.imc_set_compression(0 if args.no_compress else 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -125,8 +128,8 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.imc_profile_read(ctypes.byref(ms_p), ctypes.byref(ms_s), ctypes.byref(n_p), ctypes.byref(n_s))
     lib.imc_profile_enable(0)
-    segs, vecs, seglen, vcols = (ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64())
-    lib.imc_last_plan(ctypes.byref(segs), ctypes.byref(vecs), ctypes.byref(seglen), ctypes.byref(vcols))
+    plan = _capi.last_plan()
+    ntok0, alpha0 = forwarders[0].compressed_length(plan["token_alphabet"] or 128) if plan["vector_tokens"] else (len(forwarders[0]), 3)
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -144,7 +147,9 @@ def main():
         k_s = k_ms * 1e-3
         alg_bytes = float(local_cols) * 1.0               # 1 B of observation stream per column
         alg_flops = float(local_cols) * (2 * n_states * n_states + 3 * n_states)
-        exe_flops = float(vcols.value) * (2 * n_states * n_states + 3 * n_states)
+        exe_flops = (float(plan["vector_columns"]) * (2 * n_states * n_states + 3 * n_states)
+                     + float(plan["vector_tokens"]) * (2 * n_states * n_states))
+        kernel_name = "k_zpropagate (token kernel)" if plan["vector_tokens"] else "k_propagate (per-column kernel)"
         achieved_gbs = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
         out = {
             "metric": "alignment columns/sec (forward pass), %d-state isolation HMM" % n_states,
@@ -161,12 +166,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "states": n_states, "chunks_per_gpu": chunks_per_rank,
                        "columns_per_chunk": cols, "evals_per_s": args.steps / elapsed,
-                       "segments": segs.value, "vectors": vecs.value, "segment_len": seglen.value,
+                       "segments": plan["segments"], "vectors": plan["vectors"],
+                       "column_segment_len": plan["column_segment_len"], "token_segment_len": plan["token_segment_len"],
+                       "compression": "pair dictionary, %d tokens" % plan["token_alphabet"] if plan["vector_tokens"] else "off",
+                       "columns_per_token": (len(forwarders[0]) / max(ntok0, 1)) if plan["vector_tokens"] else 1.0,
                        "setup_s": t_setup, "loglik": value},
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "k_propagate", "kernel_ms": k_ms, "stitch_ms": ms_s.value / max(n_s.value, 1),
+                "kernel": kernel_name, "kernel_ms": k_ms, "stitch_ms": ms_s.value / max(n_s.value, 1),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "north_star names the HBM roof, but with 1 B/column the path is fp64-VALU/latency bound; "
                         "see fp64_valu",

@@ -37,6 +37,7 @@ SIGNATURES = [
     ("imc_obs_create_from_text", ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, _vpp]),
     ("imc_obs_length", ctypes.c_size_t, [ctypes.c_void_p]),
     ("imc_obs_nsym", ctypes.c_int, [ctypes.c_void_p]),
+    ("imc_obs_compressed_length", ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     ("imc_obs_free", ctypes.c_int, [ctypes.c_void_p]),
     ("imc_forward", ctypes.c_int, [_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
     ("imc_forward_batch", ctypes.c_int,
@@ -47,9 +48,11 @@ SIGNATURES = [
      [_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, ctypes.c_void_p,
       ctypes.c_void_p]),
     ("imc_set_segment_length", ctypes.c_int, [ctypes.c_size_t]),
+    ("imc_set_compression", ctypes.c_int, [ctypes.c_int]),
+    ("imc_dictionary_reset", ctypes.c_int, []),
     ("imc_profile_enable", ctypes.c_int, [ctypes.c_int]),
     ("imc_profile_read", ctypes.c_int, [_dp, _dp, _u64p, _u64p]),
-    ("imc_last_plan", ctypes.c_int, [_u64p, _u64p, _u64p, _u64p]),
+    ("imc_last_plan", ctypes.c_int, [_u64p]),
 ]
 
 _lib = None
@@ -107,3 +110,12 @@ def handle_array(handles):
     for i, h in enumerate(handles):
         arr[i] = h
     return arr
+
+
+def last_plan():
+    """Dict view of imc_last_plan()."""
+    arr = (ctypes.c_uint64 * 8)()
+    check(lib().imc_last_plan(arr))
+    keys = ("segments", "vectors", "column_segment_len", "vector_columns", "token_segment_len",
+            "vector_tokens", "tokens", "token_alphabet")
+    return dict(zip(keys, [int(x) for x in arr]))

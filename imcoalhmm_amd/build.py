@@ -10,6 +10,8 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "imcoal_fwd.hip")
 HDR = os.path.join(os.path.dirname(PKG), "include", "imcoal_fwd.h")
+DEPS = [SRC, HDR] + [os.path.join(PKG, "csrc", f) for f in
+                     ("kernels_plain.hpp", "kernels_zip.hpp", "kernels_stitch.hpp", "pair_dict.hpp")]
 LIB = os.path.join(PKG, "libimcoal_fwd.so")
 
 
@@ -24,7 +26,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(f) > t for f in (SRC, HDR))
+    return any(os.path.getmtime(f) > t for f in DEPS)
 
 
 def build_library(force=False, verbose=False):

@@ -11,13 +11,12 @@
 // order.  All rescaling is by exact powers of two (integer exponents are summed), so the only
 // difference from the textbook recursion is fp64 rounding order.
 //
-// propagate kernel (the hot kernel): lanes are grouped G lanes per vector, each lane owns R
-// consecutive states of that vector and keeps the R x N block of T' it needs in VGPRs for the whole
-// launch (T is read from HBM exactly once per lane).  Per column a lane publishes its R values to
-// LDS, reads the vector's N values back as broadcast ds_read_b128, and runs R independent fp64 FMA
-// chains.  64/G vectors ride in one wavefront; no workgroup barrier is needed because a vector never
-// leaves its wavefront.  MFMA is deliberately not used (north_star): the matrices are tiny and the
-// dependent-FMA chain, not matrix throughput, is the limit.
+// Two propagate kernels share that frame:
+//   k_propagate  (kernels_plain.hpp)  one step per alignment COLUMN; the R x N block of T' a lane needs
+//                lives in VGPRs for the whole launch, the vector is exchanged through LDS broadcasts.
+//   k_zpropagate (kernels_zip.hpp)    one step per TOKEN of the pair-compressed stream (zipHMM idea,
+//                pair_dict.hpp); the per-token operators are built per evaluation in each CU's LDS.
+// MFMA is deliberately not used (north_star): the matrices are tiny and fp64 MFMA has the VALU's rate.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -29,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <list>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -37,311 +37,10 @@
 #include <unistd.h>
 
 #include "../../include/imcoal_fwd.h"
-
-// =====================================================================================================
-// Device side
-// =====================================================================================================
-
-struct SegDesc {          // one segment of one chunk
-    const uint8_t *obs;   // first column of the segment (16-byte aligned, padded past the end)
-    uint32_t len;         // columns in this segment
-    uint32_t first;       // 1 = first segment of its chunk (single vector, starts from pi)
-};
-
-struct VecDesc {          // one propagated vector
-    uint32_t seg;         // segment id
-    uint32_t c;           // basis index (0 for a first segment)
-};
-
-struct PropArgs {
-    const SegDesc *segs;
-    const VecDesc *vecs;
-    uint32_t n_vecs;
-    int N;                 // true number of states
-    int S;                 // alphabet size
-    const double *params;  // per parameter set: pi[NP] | Tp[NP*NP] (Tp[j*NP+i]=T[j][i]) | Et[S*NP]
-    size_t pstride;        // doubles per parameter set
-    double *P;             // [B][n_vecs][NP]  normalised end vectors
-    int *EX;               // [B][n_vecs]      power-of-two exponents
-};
-
-static constexpr int WPB = 4;            // wavefronts per workgroup (256 threads)
-static constexpr int RESCALE_EVERY = 16; // columns between power-of-two rescales (= one 16-byte obs load)
-
-__device__ __forceinline__ void wave_fence()
-{
-    // A vector lives inside one wavefront and LDS executes a wavefront's DS instructions in order,
-    // so only the compiler has to be stopped from moving LDS reads across the preceding writes.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// One column for the R states of this lane:  x <- E[:,sym] .* (T' x)   (or E .* x when skipT).
-// The vector's NP values are streamed from LDS (broadcast ds_read_b128) straight into the FMA chains;
-// with SUM their total (identical in all G lanes of the vector) is returned for the rescale.
-template <int R, int NP, bool PRED, bool SUM>
-__device__ __forceinline__ void column_step(double (&xo)[R], const double (&Tb)[R][NP], double *xw, int own,
-                                            const double *Et, int sym, bool act, bool skipT, double &s)
-{
-    // emission factors first: their LDS latency hides under the FMA chains (Et is read-only)
-    double ev[R];
-    {
-        const double *e = Et + sym * NP + own;
-#pragma unroll
-        for (int k = 0; k < R; ++k) ev[k] = e[k];
-    }
-#pragma unroll
-    for (int k = 0; k < R; ++k) xw[own + k] = xo[k];
-    wave_fence();
-    double acc[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) acc[k] = 0.0;
-    if (SUM) s = 0.0;
-    const double2 *xv = reinterpret_cast<const double2 *>(xw);
-#pragma unroll
-    for (int m = 0; m < NP / 2; ++m) {
-        const double2 t = xv[m];
-#pragma unroll
-        for (int k = 0; k < R; ++k) acc[k] = fma(Tb[k][2 * m], t.x, acc[k]);
-#pragma unroll
-        for (int k = 0; k < R; ++k) acc[k] = fma(Tb[k][2 * m + 1], t.y, acc[k]);
-        if (SUM) s += t.x;
-        if (SUM) s += t.y;
-    }
-    if (NP & 1) {
-        const double t = xw[NP - 1];
-#pragma unroll
-        for (int k = 0; k < R; ++k) acc[k] = fma(Tb[k][NP - 1], t, acc[k]);
-        if (SUM) s += t;
-    }
-    wave_fence();
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        if (PRED) {
-            const double y = (skipT ? xo[k] : acc[k]) * ev[k];
-            xo[k] = act ? y : xo[k];
-        } else {
-            xo[k] = acc[k] * ev[k];
-        }
-    }
-}
-
-// Power-of-two rescale by the exponent of s (the vector's total, identical in all G lanes).
-template <int R>
-__device__ __forceinline__ void rescale(double (&xo)[R], double s, int &ex)
-{
-    int e = 0;
-    (void)frexp(s, &e);
-    e = (s > 0.0 && s < INFINITY) ? e : 0;   // 0, inf and NaN: leave the vector alone
-#pragma unroll
-    for (int k = 0; k < R; ++k) xo[k] = ldexp(xo[k], -e);
-    ex += e;
-}
-
-template <int NP>
-__device__ __forceinline__ double sum_vec(const double *xw)
-{
-    double s = 0.0;
-#pragma unroll
-    for (int j = 0; j < NP; ++j) s += xw[j];
-    return s;
-}
-
-__device__ __forceinline__ int wave_max_i32(int v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
-    return __builtin_amdgcn_readfirstlane(v);
-}
-__device__ __forceinline__ int wave_min_i32(int v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, 64));
-    return __builtin_amdgcn_readfirstlane(v);
-}
-
-template <int R, int G, int MINW>
-__global__ __launch_bounds__(WPB * 64, MINW) void k_propagate(PropArgs a)
-{
-    constexpr int NP = R * G;      // padded state count
-    constexpr int VPW = 64 / G;    // vectors per wavefront
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *Et = lds + WPB * VPW * NP;   // [S][NP]
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    int v = lane / G;
-    const int r = lane - v * G;
-    const bool spare = v >= VPW;            // leftover lanes mirror the last vector, never store
-    v = spare ? VPW - 1 : v;
-    const int own = r * R;
-    double *xw = lds + (wave * VPW + v) * NP;
-
-    const int b = blockIdx.y;
-    const double *pp = a.params + (size_t)b * a.pstride;
-    const double *pi_p = pp;
-    const double *Tp = pp + NP;
-    const double *Etg = pp + NP + NP * NP;
-
-    // stage E' once per workgroup, T' block once per lane
-    for (int i = threadIdx.x; i < a.S * NP; i += WPB * 64) Et[i] = Etg[i];
-    double Tb[R][NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j)
-#pragma unroll
-        for (int k = 0; k < R; ++k) Tb[k][j] = Tp[j * NP + own + k];
-    __syncthreads();
-
-    const uint32_t vid = (blockIdx.x * WPB + wave) * VPW + v;
-    const bool active = !spare && vid < a.n_vecs;
-    // lanes past the last vector shadow it (valid addresses, len 0, never stored)
-    const VecDesc vd = a.vecs[min(vid, a.n_vecs - 1u)];
-    const SegDesc sd = a.segs[vd.seg];
-    const int len = (vid < a.n_vecs) ? (int)sd.len : 0;
-    const bool first = sd.first != 0;
-    const uint8_t *obs = sd.obs;
-
-    double xo[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) {
-        const int i = own + k;
-        xo[k] = (vid < a.n_vecs) ? (first ? pi_p[i] : (i == (int)vd.c ? 1.0 : 0.0)) : 0.0;
-    }
-    int ex = 0;
-    double s = 0.0;
-
-    const int maxlen = wave_max_i32(len);
-    const int nfull = wave_min_i32(vid < a.n_vecs ? len / RESCALE_EVERY : INT_MAX);
-    if (maxlen == 0) return;   // wavefront entirely past the last vector (wave-uniform exit)
-
-    // ---- head: first block, column by column (column 0 of a first segment skips T') ----
-    const int head_end = min(RESCALE_EVERY, maxlen);
-    for (int t = 0; t < head_end; ++t) {
-        const bool act = t < len;
-        const int sym = act ? (int)obs[t] : 0;
-        column_step<R, NP, true, true>(xo, Tb, xw, own, Et, sym, act, first && t == 0, s);
-        rescale<R>(xo, s, ex);
-    }
-    // ---- body: full 16-column blocks common to every vector of this wavefront ----
-    for (int blk = 1; blk < nfull; ++blk) {
-        const uint4 ob = *reinterpret_cast<const uint4 *>(obs + (size_t)blk * RESCALE_EVERY);
-        uint32_t w0 = ob.x, w1 = ob.y, w2 = ob.z, w3 = ob.w;
-#pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t w = w0;
-            w0 = w1; w1 = w2; w2 = w3;
-            column_step<R, NP, false, false>(xo, Tb, xw, own, Et, w & 0xffu, true, false, s);
-            column_step<R, NP, false, false>(xo, Tb, xw, own, Et, (w >> 8) & 0xffu, true, false, s);
-            column_step<R, NP, false, false>(xo, Tb, xw, own, Et, (w >> 16) & 0xffu, true, false, s);
-            column_step<R, NP, false, true>(xo, Tb, xw, own, Et, w >> 24, true, false, s);
-        }
-        rescale<R>(xo, s, ex);
-    }
-    // ---- tail: ragged remainder, column by column ----
-    for (int t = max(RESCALE_EVERY, nfull * RESCALE_EVERY); t < maxlen; ++t) {
-        const bool act = t < len;
-        const int sym = act ? (int)obs[t] : 0;
-        column_step<R, NP, true, true>(xo, Tb, xw, own, Et, sym, act, false, s);
-        rescale<R>(xo, s, ex);
-    }
-    // ---- final normalisation: one more LDS round to see the finished vector ----
-#pragma unroll
-    for (int k = 0; k < R; ++k) xw[own + k] = xo[k];
-    wave_fence();
-    s = sum_vec<NP>(xw);
-    wave_fence();
-    rescale<R>(xo, s, ex);
-
-    if (active) {
-        double *Pout = a.P + ((size_t)b * a.n_vecs + vid) * NP + own;
-#pragma unroll
-        for (int k = 0; k < R; ++k) Pout[k] = xo[k];
-        if (r == 0) a.EX[(size_t)b * a.n_vecs + vid] = ex;
-    }
-}
-
-// EMAX[b][seg] = max_c EX[b][vec0(seg)+c]  (segments after the first of a chunk only)
-__global__ void k_emax(const uint32_t *seg_vec0, const uint8_t *seg_first, uint32_t n_segs, uint32_t n_vecs, int N,
-                       const int *EX, int *EMAX)
-{
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = blockIdx.y;
-    if (s >= n_segs) return;
-    const int *e = EX + (size_t)b * n_vecs + seg_vec0[s];
-    int m = e[0];
-    if (!seg_first[s])
-        for (int c = 1; c < N; ++c) m = max(m, e[c]);
-    EMAX[(size_t)b * n_segs + s] = m;
-}
-
-// Stitch the segment operators of one chunk in order:  a <- P_k * (a .* 2^(ex_k - emax_k)).
-// One workgroup per (chunk, parameter set); thread i owns state i.
-__global__ void k_stitch(const uint32_t *chunk_seg, const uint32_t *seg_vec0, uint32_t n_segs, uint32_t n_vecs,
-                         int N, int NP, const double *P, const int *EX, const int *EMAX, double *out, int n_chunks)
-{
-    extern __shared__ __attribute__((aligned(16))) double w[];   // [2][NPW] double buffered weights
-    const int NPW = (N + 1) & ~1;
-    const int f = blockIdx.x, b = blockIdx.y, i = threadIdx.x;
-    const uint32_t s0 = chunk_seg[f], s1 = chunk_seg[f + 1];
-    if (s0 == s1) {   // empty chunk
-        if (i == 0) out[(size_t)b * n_chunks + f] = 0.0;
-        return;
-    }
-    const double *Pb = P + (size_t)b * n_vecs * NP;
-    const int *EXb = EX + (size_t)b * n_vecs;
-    const int *EMb = EMAX + (size_t)b * n_segs;
-    double a = (i < N) ? Pb[(size_t)seg_vec0[s0] * NP + i] : 0.0;
-    long long etot = EXb[seg_vec0[s0]];
-    int buf = 0;
-    for (uint32_t k = s0 + 1; k < s1; ++k) {
-        const uint32_t v0 = seg_vec0[k];
-        const int em = EMb[k];
-        double *wb = w + buf * NPW;
-        if (i < N) wb[i] = ldexp(a, EXb[v0 + i] - em);
-        __syncthreads();
-        double acc = 0.0, s = 0.0;
-        if (i < N) {
-            const double *Pk = Pb + (size_t)v0 * NP + i;
-            for (int c = 0; c < N; ++c) {
-                const double wc = wb[c];
-                acc = fma(Pk[(size_t)c * NP], wc, acc);
-                s += wc;
-            }
-        } else {
-            for (int c = 0; c < N; ++c) s += wb[c];
-        }
-        int e = 0;
-        (void)frexp(s, &e);
-        e = (s > 0.0 && s < INFINITY) ? e : 0;
-        a = ldexp(acc, -e);
-        etot += (long long)em + e;
-        buf ^= 1;   // next iteration writes the other buffer: one barrier per step suffices
-    }
-    // total = sum_i a_i, by thread 0 through LDS
-    __syncthreads();
-    if (i < N) w[i] = a;
-    __syncthreads();
-    if (i == 0) {
-        double tot = 0.0;
-        for (int c = 0; c < N; ++c) tot += w[c];
-        out[(size_t)b * n_chunks + f] = (double)etot * 0.693147180559945309417232121458 + log(tot);
-    }
-}
-
-// partial[b] = sum_f per_chunk[b][f], left to right from 0.0 (likelihood.py:33)
-__global__ void k_sum_chunks(const double *per_chunk, int n_chunks, int B, double *partial)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double t = 0.0;
-    for (int f = 0; f < n_chunks; ++f) t += per_chunk[(size_t)b * n_chunks + f];
-    partial[b] = t;
-}
-
-// =====================================================================================================
-// Host side
-// =====================================================================================================
+#include "kernels_plain.hpp"
+#include "kernels_stitch.hpp"
+#include "kernels_zip.hpp"
+#include "pair_dict.hpp"
 
 namespace {
 
@@ -362,19 +61,34 @@ int fail(int code, const std::string &msg)
                         std::string(#expr) + ": " + hipGetErrorString(_e));                             \
     } while (0)
 
+constexpr size_t LDS_BUDGET = 160 * 1024 - 1024;   // bytes of LDS a compressed-path workgroup may use
+constexpr size_t ZIP_MIN_COLUMNS = 4096;           // shorter chunks are not worth compressing
+constexpr size_t DICT_TRAIN_MIN = 32768;           // first chunk at least this long trains the dictionary
+constexpr size_t DICT_TRAIN_MAX = 8u << 20;        // train on at most this prefix
+
+struct DictDev {                                   // one trained dictionary + its device copy
+    imc::PairDict dict;
+    uint8_t *d_left = nullptr, *d_right = nullptr;
+};
+
+struct Ev3 { hipEvent_t a, b, c; };   // a: before propagate, b: after propagate, c: after stitch
+
 struct Ctx {
     pid_t pid = 0;
     int device = -1;          // -1: use the thread's current device at first use
     bool ready = false;
     hipStream_t stream = nullptr;
     int cus = 256;
-    uint64_t next_obs_id = 1;
+    uint64_t next_obs_id = 1, next_dict_id = 1;
     size_t seg_override = 0;
+    int compression = 1;      // 0 = plain per-column kernel only, 1 = automatic
     bool profile = false;
-    struct Ev3 { hipEvent_t a, b, c; };   // a: before propagate, b: after propagate, c: after stitch
     std::vector<Ev3> events;
-    uint64_t last_segments = 0, last_vectors = 0, last_seglen = 0, last_vcols = 0;
+    std::map<int, std::shared_ptr<DictDev>> dicts;   // by raw alphabet size
+    uint64_t last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 } g;
+
+void drop_plans();
 
 int ensure_ctx()
 {
@@ -385,6 +99,7 @@ int ensure_ctx()
         g.ready = false;
         g.stream = nullptr;
         g.events.clear();
+        g.dicts.clear();
     }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -415,12 +130,37 @@ struct imc_obs {
     int device;
     int nsym;
     size_t L;
-    uint8_t *d_sym;   // L bytes + zero padding
+    uint8_t *d_sym;                        // L raw symbols + zero padding
+    std::shared_ptr<DictDev> dict;         // null: not compressed
+    uint8_t *d_tok[imc::kNumLevels];       // token streams per level (aliases allowed), null if none
+    size_t ntok[imc::kNumLevels];
+    int alphabet[imc::kNumLevels];
 };
 
 namespace {
 
 constexpr size_t OBS_PAD = 256;
+
+hipError_t upload_padded(const uint8_t *host, size_t n, uint8_t **dptr)
+{
+    const size_t bytes = ((n + OBS_PAD - 1) / OBS_PAD) * OBS_PAD + OBS_PAD;
+    hipError_t e = hipMalloc((void **)dptr, bytes);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(*dptr, 0, bytes, g.stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(*dptr, host, n, hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    return e;
+}
+
+void obs_release(imc_obs *o)
+{
+    (void)hipFree(o->d_sym);
+    for (int l = 0; l < imc::kNumLevels; ++l) {
+        bool alias = false;
+        for (int m = 0; m < l; ++m) alias |= (o->d_tok[m] == o->d_tok[l]);
+        if (o->d_tok[l] && !alias) (void)hipFree(o->d_tok[l]);
+    }
+}
 
 int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
 {
@@ -433,66 +173,139 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
     o->nsym = nsym;
     o->L = L;
     o->d_sym = nullptr;
-    const size_t bytes = ((L + OBS_PAD - 1) / OBS_PAD) * OBS_PAD + OBS_PAD;
-    hipError_t e = hipMalloc((void **)&o->d_sym, bytes);
+    for (int l = 0; l < imc::kNumLevels; ++l) { o->d_tok[l] = nullptr; o->ntok[l] = 0; o->alphabet[l] = nsym; }
+    hipError_t e = upload_padded(host, L, &o->d_sym);
     if (e != hipSuccess) {
         delete o;
-        return fail(IMC_ERR_OOM, std::string("hipMalloc(observations): ") + hipGetErrorString(e));
+        return fail(e == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
+                    std::string("observation upload: ") + hipGetErrorString(e));
     }
-    e = hipMemsetAsync(o->d_sym, 0, bytes, g.stream);
-    if (e == hipSuccess && L) e = hipMemcpyAsync(o->d_sym, host, L, hipMemcpyHostToDevice, g.stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
-    if (e != hipSuccess) {
-        (void)hipFree(o->d_sym);
-        delete o;
-        return fail(IMC_ERR_HIP, std::string("observation upload: ") + hipGetErrorString(e));
+    // ---- compression (the preprocess_raw_observations analogue, hmm.py:16) ----
+    if (g.compression && L >= ZIP_MIN_COLUMNS && nsym <= imc::kLevels[imc::kNumLevels - 1] / 2) {
+        std::shared_ptr<DictDev> dd;
+        auto it = g.dicts.find(nsym);
+        if (it != g.dicts.end()) dd = it->second;
+        else if (L >= DICT_TRAIN_MIN) {
+            dd = std::make_shared<DictDev>();
+            const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
+            imc::train_dict(dd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64);
+            dd->dict.id = g.next_dict_id++;
+            hipError_t e2 = hipMalloc((void **)&dd->d_left, imc::kMaxAlphabet);
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&dd->d_right, imc::kMaxAlphabet);
+            if (e2 == hipSuccess) e2 = hipMemcpy(dd->d_left, dd->dict.left, imc::kMaxAlphabet, hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(dd->d_right, dd->dict.right, imc::kMaxAlphabet, hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) {
+                obs_release(o);
+                delete o;
+                return fail(IMC_ERR_HIP, std::string("dictionary upload: ") + hipGetErrorString(e2));
+            }
+            g.dicts[nsym] = dd;
+        }
+        if (dd && dd->dict.alphabet > nsym) {
+            imc::EncodedLevels enc;
+            imc::encode_levels(dd->dict, host, L, enc);
+            o->dict = dd;
+            for (int l = 0; l < imc::kNumLevels; ++l) {
+                o->alphabet[l] = enc.alphabet[l];
+                o->ntok[l] = enc.streams[l].size();
+                if (l > 0 && enc.alphabet[l] == enc.alphabet[l - 1]) { o->d_tok[l] = o->d_tok[l - 1]; continue; }
+                if (enc.alphabet[l] <= nsym) { o->d_tok[l] = nullptr; continue; }   // raw stream: use d_sym
+                hipError_t e3 = upload_padded(enc.streams[l].data(), enc.streams[l].size(), &o->d_tok[l]);
+                if (e3 != hipSuccess) {
+                    obs_release(o);
+                    delete o;
+                    return fail(e3 == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
+                                std::string("token stream upload: ") + hipGetErrorString(e3));
+                }
+            }
+        }
     }
     *out = o;
     return IMC_OK;
 }
 
-// ---- launch plan: segmentation of a list of chunks for given (N, B) -------------------------------
+// ---- kernel table ---------------------------------------------------------------------------------
+
+using ChainFn = void (*)(const ChainDesc *, int, const uint32_t *, uint32_t, uint32_t, const double *, const int *,
+                         const int *, uint32_t, double *, int *);
 
 struct KernelChoice {
     int R, G, NP, VPW, minw;
-    void (*fn)(PropArgs);
+    void (*plain)(PropArgs);
+    void (*zip)(PropArgs);
+    size_t (*zip_lds)(int);
+    ChainFn chain;
+    bool zip_attr_set;
 };
 
-#define KC(R_, G_, MW_) KernelChoice{R_, G_, (R_) * (G_), 64 / (G_), MW_, k_propagate<R_, G_, MW_>}
-const KernelChoice kChoices[] = {
-    KC(4, 1, 2), KC(4, 2, 2), KC(4, 3, 2), KC(4, 4, 2), KC(4, 5, 2), KC(3, 8, 2), KC(2, 14, 2), KC(2, 16, 2),
-    KC(2, 20, 1), KC(1, 48, 1), KC(1, 56, 1), KC(1, 64, 1),
+template <int R, int G, int MW>
+KernelChoice make_kc()
+{
+    constexpr int NP = R * G;
+    return KernelChoice{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
+                        k_chain<NP, (NP <= 32)>, false};
+}
+
+KernelChoice kChoices[] = {
+    make_kc<4, 1, 2>(), make_kc<4, 2, 2>(), make_kc<4, 3, 2>(), make_kc<4, 4, 2>(), make_kc<4, 5, 2>(),
+    make_kc<3, 8, 2>(), make_kc<2, 14, 2>(), make_kc<2, 16, 2>(), make_kc<2, 20, 1>(), make_kc<1, 48, 1>(),
+    make_kc<1, 56, 1>(), make_kc<1, 64, 1>(),
 };
-#undef KC
 constexpr int IMC_MAX_N = 64;
 
-const KernelChoice *choose_kernel(int N)
+KernelChoice *choose_kernel(int N)
 {
-    for (const auto &k : kChoices)
+    for (auto &k : kChoices)
         if (k.NP >= N) return &k;
     return nullptr;
 }
 
+// ---- launch plan ----------------------------------------------------------------------------------
+
+struct Group {             // one propagate launch
+    bool zip = false;
+    int level = -1, A = 0;
+    std::shared_ptr<DictDev> dict;
+    std::vector<int> chunks;
+    uint32_t vec_begin = 0, n_vecs = 0;
+    size_t seglen = 0;
+    uint64_t vsteps = 0;   // executed vector-steps per parameter set (columns or tokens)
+    uint64_t stream_len = 0;
+};
+
+struct Level {             // one level of the stitch hierarchy (level 0 = propagate output)
+    uint32_t n_segs = 0, n_vecs = 0, n_chains = 0;
+    uint32_t *d_vec0 = nullptr;
+    uint8_t *d_first = nullptr;
+    ChainDesc *d_chains = nullptr;   // chains that produce THIS level from the previous one
+    double *d_P = nullptr;
+    int *d_EX = nullptr, *d_EMAX = nullptr;
+    void release()
+    {
+        (void)hipFree(d_vec0); (void)hipFree(d_first); (void)hipFree(d_chains);
+        (void)hipFree(d_P); (void)hipFree(d_EX); (void)hipFree(d_EMAX);
+    }
+};
+
 struct Plan {
-    std::vector<uint64_t> key;   // obs ids..., N, S, B, seg_override
-    const KernelChoice *kc = nullptr;
+    std::vector<uint64_t> key;
+    KernelChoice *kc = nullptr;
     int N = 0, S = 0, B = 0, n_chunks = 0;
     uint32_t n_segs = 0, n_vecs = 0;
-    size_t seglen = 0;
-    uint64_t vcols = 0;          // executed vector-columns per parameter set
+    std::vector<Group> groups;
     size_t pstride = 0;
     SegDesc *d_segs = nullptr;
     VecDesc *d_vecs = nullptr;
-    uint32_t *d_seg_vec0 = nullptr, *d_chunk_seg = nullptr;
-    uint8_t *d_seg_first = nullptr;
-    double *d_params = nullptr, *d_P = nullptr, *d_out = nullptr, *d_partial = nullptr;
-    int *d_EX = nullptr, *d_EMAX = nullptr;
+    std::vector<Level> levels;       // levels[0] holds the propagate output
+    int32_t *d_final_vec = nullptr;  // per chunk: vector index in the last level, -1 for an empty chunk
+    uint64_t chain_steps = 0;        // serial depth of the stitch (sum over levels of the longest chain)
+    double *d_params = nullptr, *d_out = nullptr;
     double *h_params = nullptr, *h_out = nullptr;   // pinned
     void release()
     {
-        (void)hipFree(d_segs); (void)hipFree(d_vecs); (void)hipFree(d_seg_vec0); (void)hipFree(d_chunk_seg);
-        (void)hipFree(d_seg_first); (void)hipFree(d_params); (void)hipFree(d_P); (void)hipFree(d_out);
-        (void)hipFree(d_partial); (void)hipFree(d_EX); (void)hipFree(d_EMAX);
+        (void)hipFree(d_segs); (void)hipFree(d_vecs); (void)hipFree(d_final_vec);
+        for (auto &l : levels) l.release();
+        (void)hipFree(d_params); (void)hipFree(d_out);
         (void)hipHostFree(h_params); (void)hipHostFree(h_out);
     }
 };
@@ -508,21 +321,19 @@ void drop_plans()
 
 size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
-// Pick the segment length that minimises a simple machine model: equal-length wavefront tasks are
-// executed in rounds of `resident` wavefronts; the serial stitch adds ~stitch_cost per segment of the
-// longest chunk.
-size_t choose_seglen(const std::vector<size_t> &lens, int N, int B, const KernelChoice *kc, int cus)
+// Pick the segment length (in stream elements) that minimises a simple machine model: equal-length
+// wavefront tasks run in rounds of `resident` wavefronts at `step_cost` cycles per step; the serial
+// stitch adds ~stitch_cost per segment of the longest chunk.
+size_t choose_seglen(const std::vector<size_t> &lens, int N, int B, int VPW, double resident, double step_cost)
 {
     size_t maxlen = 0;
     for (size_t L : lens) maxlen = std::max(maxlen, L);
-    if (maxlen <= 1024) return std::max<size_t>(maxlen, 16);
-    const double resident = (double)cus * 4.0 * kc->minw;
-    const double col_cost = 4.0 * kc->R * kc->NP + 120.0;   // cycles per column per wavefront (issue + LDS)
-    const double stitch_cost = 4.0 * N + 400.0;              // cycles per stitched segment
+    if (maxlen <= 256) return std::max<size_t>(round_up(maxlen, 16), 16);
+    const double stitch_cost = 12.0 * N + 300.0;   // cycles per stitched segment
     double best = 1e300;
     size_t best_seg = maxlen;
-    for (double s = 1024.0; ; s *= 1.189207115) {
-        size_t seg = std::min(round_up((size_t)s, 16), round_up(maxlen, 16));
+    for (double s = 128.0;; s *= 1.189207115) {
+        const size_t seg = std::min(round_up((size_t)s, 16), round_up(maxlen, 16));
         double vecs = 0.0, kmax = 0.0;
         for (size_t L : lens) {
             if (!L) continue;
@@ -530,9 +341,9 @@ size_t choose_seglen(const std::vector<size_t> &lens, int N, int B, const Kernel
             vecs += 1.0 + (K - 1.0) * N;
             kmax = std::max(kmax, K);
         }
-        const double waves = std::ceil(vecs * B / kc->VPW);
+        const double waves = std::ceil(vecs * B / VPW);
         const double rounds = std::ceil(waves / resident);
-        const double cost = rounds * (double)seg * col_cost + kmax * stitch_cost;
+        const double cost = rounds * (double)seg * step_cost + kmax * stitch_cost;
         if (cost < best) { best = cost; best_seg = seg; }
         if (seg >= maxlen) break;
     }
@@ -542,10 +353,10 @@ size_t choose_seglen(const std::vector<size_t> &lens, int N, int B, const Kernel
 int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, Plan **out)
 {
     std::vector<uint64_t> key;
-    key.reserve(n_chunks + 4);
+    key.reserve(n_chunks + 5);
     for (int f = 0; f < n_chunks; ++f) key.push_back(chunks[f]->id);
     key.push_back((uint64_t)N); key.push_back((uint64_t)S); key.push_back((uint64_t)B);
-    key.push_back((uint64_t)g.seg_override);
+    key.push_back((uint64_t)g.seg_override); key.push_back((uint64_t)g.compression);
     for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
         if ((*it)->key == key) {
             g_plans.splice(g_plans.begin(), g_plans, it);
@@ -553,49 +364,131 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             return IMC_OK;
         }
     }
-    const KernelChoice *kc = choose_kernel(N);
+    KernelChoice *kc = choose_kernel(N);
     if (!kc) return fail(IMC_ERR_ARG, "N exceeds the largest built kernel (" + std::to_string(IMC_MAX_N) + ")");
     auto p = std::make_unique<Plan>();
     p->key = key; p->kc = kc; p->N = N; p->S = S; p->B = B; p->n_chunks = n_chunks;
 
-    std::vector<size_t> lens(n_chunks);
-    for (int f = 0; f < n_chunks; ++f) lens[f] = chunks[f]->L;
-    size_t seg = g.seg_override ? round_up(std::max<size_t>(g.seg_override, 16), 16)
-                                : choose_seglen(lens, N, B, kc, g.cus);
-    p->seglen = seg;
-
+    // ---- assign chunks to launch groups: plain, or (dictionary, level) ----
+    int a_max = 0;   // largest alphabet whose operator table fits LDS for this N
+    for (int A = 1; A <= imc::kMaxAlphabet; ++A)
+        if (kc->zip_lds(A) <= LDS_BUDGET) a_max = A;
+    std::vector<int> chunk_group(n_chunks, -1);
+    for (int f = 0; f < n_chunks; ++f) {
+        const imc_obs *o = chunks[f];
+        int level = -1;
+        if (g.compression && o->dict && o->nsym == S)
+            for (int l = 0; l < imc::kNumLevels; ++l)
+                if (o->alphabet[l] <= a_max && o->alphabet[l] > o->nsym && o->d_tok[l]) level = l;
+        int gi = -1;
+        for (size_t q = 0; q < p->groups.size(); ++q) {
+            Group &gr = p->groups[q];
+            if (level < 0 ? !gr.zip : (gr.zip && gr.level == level && gr.dict == o->dict)) gi = (int)q;
+        }
+        if (gi < 0) {
+            Group gr;
+            gr.zip = level >= 0;
+            gr.level = level;
+            if (gr.zip) { gr.dict = o->dict; gr.A = o->alphabet[level]; }
+            p->groups.push_back(gr);
+            gi = (int)p->groups.size() - 1;
+        }
+        p->groups[gi].chunks.push_back(f);
+        chunk_group[f] = gi;
+    }
+    // ---- segment length per group ----
+    for (Group &gr : p->groups) {
+        std::vector<size_t> lens;
+        for (int f : gr.chunks) lens.push_back(gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L);
+        if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);
+        else if (gr.zip) {
+            // LDS-bound: a workgroup of ZWAVES wavefronts serialises on one CU's LDS
+            const double lds_cycles = ((double)kc->R * kc->NP / 2 + kc->NP / 2.0) * 4.0 + kc->R * 6.0 + 40.0;
+            gr.seglen = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * ZWAVES, lds_cycles * ZWAVES / 4.0);
+        } else {
+            gr.seglen = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * 4.0 * kc->minw,
+                                      4.0 * kc->R * kc->NP + 120.0);
+        }
+    }
+    // ---- segments in chunk order ----
     std::vector<SegDesc> segs;
-    std::vector<VecDesc> vecs;
-    std::vector<uint32_t> seg_vec0, chunk_seg(n_chunks + 1, 0);
     std::vector<uint8_t> seg_first;
-    uint64_t vcols = 0;
+    std::vector<uint32_t> chunk_seg(n_chunks + 1, 0);
     for (int f = 0; f < n_chunks; ++f) {
         chunk_seg[f] = (uint32_t)segs.size();
-        const size_t L = lens[f];
-        if (L) {
-            const size_t K0 = (L + seg - 1) / seg;
-            const size_t sl = round_up((L + K0 - 1) / K0, 16);   // equalised, multiple of 16
-            for (size_t off = 0, k = 0; off < L; off += sl, ++k) {
-                const size_t n = std::min(sl, L - off);
-                SegDesc d{chunks[f]->d_sym + off, (uint32_t)n, k == 0 ? 1u : 0u};
-                const uint32_t sid = (uint32_t)segs.size();
-                segs.push_back(d);
-                seg_first.push_back(k == 0);
-                seg_vec0.push_back((uint32_t)vecs.size());
-                const int nv = (k == 0) ? 1 : N;
-                for (int c = 0; c < nv; ++c) vecs.push_back(VecDesc{sid, (uint32_t)c});
-                vcols += (uint64_t)nv * n;
-            }
+        const Group &gr = p->groups[chunk_group[f]];
+        const size_t L = gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L;
+        const uint8_t *base = gr.zip ? chunks[f]->d_tok[gr.level] : chunks[f]->d_sym;
+        if (!L) continue;
+        const size_t K0 = (L + gr.seglen - 1) / gr.seglen;
+        const size_t sl = round_up((L + K0 - 1) / K0, 16);   // equalised, multiple of 16
+        for (size_t off = 0, k = 0; off < L; off += sl, ++k) {
+            segs.push_back(SegDesc{base + off, (uint32_t)std::min(sl, L - off), k == 0 ? 1u : 0u});
+            seg_first.push_back(k == 0);
         }
     }
     chunk_seg[n_chunks] = (uint32_t)segs.size();
+    // ---- vectors, contiguous per group ----
+    std::vector<VecDesc> vecs;
+    std::vector<uint32_t> seg_vec0(segs.size(), 0);
+    for (Group &gr : p->groups) {
+        gr.vec_begin = (uint32_t)vecs.size();
+        for (int f : gr.chunks) {
+            gr.stream_len += gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L;
+            for (uint32_t sid = chunk_seg[f]; sid < chunk_seg[f + 1]; ++sid) {
+                seg_vec0[sid] = (uint32_t)vecs.size();
+                const int nv = seg_first[sid] ? 1 : N;
+                for (int c = 0; c < nv; ++c) vecs.push_back(VecDesc{sid, (uint32_t)c});
+                gr.vsteps += (uint64_t)nv * segs[sid].len;
+            }
+        }
+        gr.n_vecs = (uint32_t)vecs.size() - gr.vec_begin;
+    }
     if (vecs.size() >= (size_t)UINT32_MAX / 2) return fail(IMC_ERR_ARG, "too many vectors in one call");
     p->n_segs = (uint32_t)segs.size();
     p->n_vecs = (uint32_t)vecs.size();
-    p->vcols = vcols;
     p->pstride = round_up((size_t)kc->NP + (size_t)kc->NP * kc->NP + (size_t)S * kc->NP, 2);
 
-    // keep at most MAX_PLANS plans alive
+    // ---- stitch hierarchy: fold runs of g ~ sqrt(K) consecutive segments until one vector per chunk ----
+    struct HostLevel { std::vector<uint32_t> chunk_seg, vec0; std::vector<uint8_t> first; std::vector<ChainDesc> chains; uint32_t n_vecs; };
+    std::vector<HostLevel> hl(1);
+    hl[0].chunk_seg = chunk_seg; hl[0].vec0 = seg_vec0; hl[0].first = seg_first; hl[0].n_vecs = p->n_vecs;
+    for (;;) {
+        const HostLevel &cur = hl.back();
+        uint32_t kmax = 0;
+        for (int f = 0; f < n_chunks; ++f) kmax = std::max(kmax, cur.chunk_seg[f + 1] - cur.chunk_seg[f]);
+        // a level whose chunks all hold one first-vector is final; level 0 operators always need one pass
+        if (kmax <= 1 && hl.size() > 1) break;
+        if (kmax == 0) break;
+        const uint32_t gsz = kmax <= 12 ? kmax : (uint32_t)std::ceil(std::sqrt((double)kmax));
+        p->chain_steps += gsz;
+        HostLevel nx;
+        nx.chunk_seg.assign(n_chunks + 1, 0);
+        nx.n_vecs = 0;
+        for (int f = 0; f < n_chunks; ++f) {
+            nx.chunk_seg[f] = (uint32_t)nx.vec0.size();
+            const uint32_t s0 = cur.chunk_seg[f], s1 = cur.chunk_seg[f + 1];
+            for (uint32_t rb = s0; rb < s1; rb += gsz) {
+                const uint32_t re = std::min(rb + gsz, s1);
+                const bool fst = rb == s0;
+                nx.vec0.push_back(nx.n_vecs);
+                nx.first.push_back(fst);
+                const int nvv = fst ? 1 : N;
+                for (int c = 0; c < nvv; ++c) nx.chains.push_back(ChainDesc{rb, re, (uint32_t)c, nx.n_vecs + c, fst ? 1u : 0u, 0u});
+                nx.n_vecs += nvv;
+            }
+        }
+        nx.chunk_seg[n_chunks] = (uint32_t)nx.vec0.size();
+        const bool done = kmax <= gsz;
+        hl.push_back(std::move(nx));
+        if (done) break;
+    }
+    std::vector<int32_t> final_vec(std::max(n_chunks, 1), -1);
+    for (int f = 0; f < n_chunks; ++f) {
+        const HostLevel &last = hl.back();
+        if (last.chunk_seg[f + 1] > last.chunk_seg[f]) final_vec[f] = (int32_t)last.vec0[last.chunk_seg[f]];
+    }
+
     while (g_plans.size() >= MAX_PLANS) { g_plans.back()->release(); g_plans.pop_back(); }
 
     Plan *q = p.get();
@@ -605,19 +498,31 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         if (bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
         return e;
     };
+    auto zalloc = [&](void **d, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 16));
+        if (e == hipSuccess) e = hipMemset(*d, 0, std::max<size_t>(bytes, 16));   // padded operator columns stay 0
+        return e;
+    };
     hipError_t e = hipSuccess;
-    const size_t nv = std::max<size_t>(q->n_vecs, 1), ns = std::max<size_t>(q->n_segs, 1);
     if (e == hipSuccess) e = up((void **)&q->d_segs, segs.data(), segs.size() * sizeof(SegDesc));
     if (e == hipSuccess) e = up((void **)&q->d_vecs, vecs.data(), vecs.size() * sizeof(VecDesc));
-    if (e == hipSuccess) e = up((void **)&q->d_seg_vec0, seg_vec0.data(), seg_vec0.size() * 4);
-    if (e == hipSuccess) e = up((void **)&q->d_seg_first, seg_first.data(), seg_first.size());
-    if (e == hipSuccess) e = up((void **)&q->d_chunk_seg, chunk_seg.data(), chunk_seg.size() * 4);
+    if (e == hipSuccess) e = up((void **)&q->d_final_vec, final_vec.data(), final_vec.size() * 4);
+    q->levels.resize(hl.size());
+    for (size_t l = 0; l < hl.size() && e == hipSuccess; ++l) {
+        Level &lv = q->levels[l];
+        lv.n_segs = (uint32_t)hl[l].vec0.size();
+        lv.n_vecs = hl[l].n_vecs;
+        lv.n_chains = (uint32_t)hl[l].chains.size();
+        const size_t nv = std::max<size_t>(lv.n_vecs, 1), ns = std::max<size_t>(lv.n_segs, 1);
+        e = up((void **)&lv.d_vec0, hl[l].vec0.data(), hl[l].vec0.size() * 4);
+        if (e == hipSuccess) e = up((void **)&lv.d_first, hl[l].first.data(), hl[l].first.size());
+        if (e == hipSuccess) e = up((void **)&lv.d_chains, hl[l].chains.data(), hl[l].chains.size() * sizeof(ChainDesc));
+        if (e == hipSuccess) e = zalloc((void **)&lv.d_P, (size_t)B * nv * kc->NP * 8);
+        if (e == hipSuccess) e = zalloc((void **)&lv.d_EX, (size_t)B * nv * 4);
+        if (e == hipSuccess) e = zalloc((void **)&lv.d_EMAX, (size_t)B * ns * 4);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_params, (size_t)B * q->pstride * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&q->d_P, (size_t)B * nv * kc->NP * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&q->d_EX, (size_t)B * nv * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&q->d_EMAX, (size_t)B * ns * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_out, (size_t)B * std::max(n_chunks, 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&q->d_partial, (size_t)B * 8);
     if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_params, (size_t)B * q->pstride * 8, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_out, (size_t)B * std::max(n_chunks, 1) * 8, hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -650,7 +555,7 @@ int check_args(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, 
 // Enqueue everything for one batch on `stream`.  Results land in plan->d_out ([B][n_chunks]).
 int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipStream_t stream)
 {
-    const KernelChoice *kc = p->kc;
+    KernelChoice *kc = p->kc;
     const int N = p->N, S = p->S, NP = kc->NP, B = p->B;
     // pad parameters into the pinned staging buffer
     for (int b = 0; b < B; ++b) {
@@ -666,37 +571,64 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
     }
     HIP_TRY(hipMemcpyAsync(p->d_params, p->h_params, (size_t)B * p->pstride * 8, hipMemcpyHostToDevice, stream));
 
-    g.last_segments = p->n_segs; g.last_vectors = p->n_vecs; g.last_seglen = p->seglen;
-    g.last_vcols = p->vcols * (uint64_t)B;
-    if (p->n_vecs) {
+    uint64_t *lp = g.last_plan;
+    lp[0] = p->n_segs; lp[1] = p->n_vecs; lp[2] = lp[3] = lp[4] = lp[5] = lp[6] = lp[7] = 0;
+    Ev3 ev{nullptr, nullptr, nullptr};
+    const bool prof = g.profile && p->n_vecs;
+    if (prof) {
+        HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); HIP_TRY(hipEventCreate(&ev.c));
+        HIP_TRY(hipEventRecord(ev.a, stream));
+    }
+    for (const Group &gr : p->groups) {
+        if (!gr.n_vecs) continue;
         PropArgs a;
-        a.segs = p->d_segs; a.vecs = p->d_vecs; a.n_vecs = p->n_vecs; a.N = N; a.S = S;
-        a.params = p->d_params; a.pstride = p->pstride; a.P = p->d_P; a.EX = p->d_EX;
-        const uint32_t vpb = (uint32_t)(WPB * kc->VPW);
-        dim3 grid((p->n_vecs + vpb - 1) / vpb, (unsigned)B);
-        const size_t lds = ((size_t)WPB * kc->VPW * NP + (size_t)S * NP) * 8;
-        Ctx::Ev3 ev{nullptr, nullptr, nullptr};
-        if (g.profile) {
-            HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); HIP_TRY(hipEventCreate(&ev.c));
-            HIP_TRY(hipEventRecord(ev.a, stream));
+        a.segs = p->d_segs; a.vecs = p->d_vecs + gr.vec_begin; a.n_vecs = gr.n_vecs; a.vec_base = gr.vec_begin;
+        a.n_vecs_total = p->n_vecs; a.N = N; a.S = S;
+        a.params = p->d_params; a.pstride = p->pstride; a.P = p->levels[0].d_P; a.EX = p->levels[0].d_EX;
+        a.A = gr.A; a.tok_left = gr.zip ? gr.dict->d_left : nullptr; a.tok_right = gr.zip ? gr.dict->d_right : nullptr;
+        if (gr.zip) {
+            const size_t lds = kc->zip_lds(gr.A);
+            if (!kc->zip_attr_set) {
+                HIP_TRY(hipFuncSetAttribute((const void *)kc->zip, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)LDS_BUDGET));
+                kc->zip_attr_set = true;
+            }
+            const uint32_t vpb = (uint32_t)(ZWAVES * kc->VPW);
+            dim3 grid((gr.n_vecs + vpb - 1) / vpb, (unsigned)B);
+            hipLaunchKernelGGL(kc->zip, grid, dim3(ZWAVES * 64), lds, stream, a);
+            lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
+        } else {
+            const uint32_t vpb = (uint32_t)(WPB * kc->VPW);
+            dim3 grid((gr.n_vecs + vpb - 1) / vpb, (unsigned)B);
+            const size_t lds = ((size_t)WPB * kc->VPW * NP + (size_t)S * NP) * 8;
+            hipLaunchKernelGGL(kc->plain, grid, dim3(WPB * 64), lds, stream, a);
+            lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B;
         }
-        hipLaunchKernelGGL(kc->fn, grid, dim3(WPB * 64), lds, stream, a);
         HIP_TRY(hipGetLastError());
-        if (g.profile) HIP_TRY(hipEventRecord(ev.b, stream));
-        hipLaunchKernelGGL(k_emax, dim3((p->n_segs + 255) / 256, (unsigned)B), dim3(256), 0, stream,
-                           p->d_seg_vec0, p->d_seg_first, p->n_segs, p->n_vecs, N, p->d_EX, p->d_EMAX);
+    }
+    if (prof) HIP_TRY(hipEventRecord(ev.b, stream));
+    for (size_t l = 0; l + 1 < p->levels.size(); ++l) {
+        const Level &in = p->levels[l], &ot = p->levels[l + 1];
+        if (!in.n_segs || !ot.n_chains) continue;
+        hipLaunchKernelGGL(k_emax, dim3((in.n_segs + 255) / 256, (unsigned)B), dim3(256), 0, stream,
+                           in.d_vec0, in.d_first, in.n_segs, in.n_vecs, N, in.d_EX, in.d_EMAX);
         HIP_TRY(hipGetLastError());
-        if (g.profile) g.events.push_back(ev);
+        const int threads = (int)round_up((size_t)NP, 64);
+        hipLaunchKernelGGL(kc->chain, dim3(ot.n_chains, (unsigned)B), dim3(threads), 0, stream,
+                           ot.d_chains, N, in.d_vec0, in.n_segs, in.n_vecs, in.d_P, in.d_EX, in.d_EMAX,
+                           ot.n_vecs, ot.d_P, ot.d_EX);
+        HIP_TRY(hipGetLastError());
     }
     if (p->n_chunks) {
-        const int threads = (int)round_up((size_t)N, 64);
-        const size_t lds = 2 * (size_t)((N + 1) & ~1) * 8;
-        hipLaunchKernelGGL(k_stitch, dim3((unsigned)p->n_chunks, (unsigned)B), dim3(threads), lds, stream,
-                           p->d_chunk_seg, p->d_seg_vec0, p->n_segs, p->n_vecs, N, NP, p->d_P, p->d_EX,
-                           p->d_EMAX, p->d_out, p->n_chunks);
+        const Level &last = p->levels.back();
+        hipLaunchKernelGGL(k_finish, dim3((p->n_chunks + 63) / 64, (unsigned)B), dim3(64), 0, stream,
+                           p->d_final_vec, p->n_chunks, N, NP, last.n_vecs, last.d_P, last.d_EX, p->d_out);
         HIP_TRY(hipGetLastError());
     }
-    if (g.profile && p->n_vecs) HIP_TRY(hipEventRecord(g.events.back().c, stream));
+    if (prof) {
+        HIP_TRY(hipEventRecord(ev.c, stream));
+        g.events.push_back(ev);
+    }
     return IMC_OK;
 }
 
@@ -733,7 +665,7 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
 
 extern "C" {
 
-const char *imc_version(void) { return "imcoal_fwd 0.1 (gfx950)"; }
+const char *imc_version(void) { return "imcoal_fwd 0.2 (gfx950)"; }
 const char *imc_last_error(void) { return g_err.c_str(); }
 
 int imc_device_count(void)
@@ -749,6 +681,7 @@ int imc_set_device(int device)
     if (device < 0) return fail(IMC_ERR_ARG, "negative device index");
     if (g.ready && g.pid == getpid() && g.device != device) {
         drop_plans();
+        g.dicts.clear();
         (void)hipStreamDestroy(g.stream);
         g.ready = false;
     }
@@ -762,7 +695,7 @@ int imc_obs_create(const uint8_t *sym, size_t L, int nsym, imc_obs **out)
     if (!out) return fail(IMC_ERR_ARG, "out is null");
     if (nsym < 1 || nsym > 256) return fail(IMC_ERR_ARG, "nsym must be in [1,256]");
     if (L && !sym) return fail(IMC_ERR_ARG, "sym is null");
-    if (L >= (size_t)1 << 40) return fail(IMC_ERR_ARG, "chunk too long");
+    if (L >= (size_t)1 << 31) return fail(IMC_ERR_ARG, "chunk too long (limit 2^31-1 columns per chunk)");
     for (size_t t = 0; t < L; ++t)
         if (sym[t] >= nsym) return fail(IMC_ERR_SYMBOL, "symbol " + std::to_string(sym[t]) + " at column " + std::to_string(t) + " >= nsym");
     return obs_upload(sym, L, nsym, out);
@@ -773,6 +706,7 @@ int imc_obs_create_i32(const int32_t *sym, size_t L, int nsym, imc_obs **out)
     if (!out) return fail(IMC_ERR_ARG, "out is null");
     if (nsym < 1 || nsym > 256) return fail(IMC_ERR_ARG, "nsym must be in [1,256]");
     if (L && !sym) return fail(IMC_ERR_ARG, "sym is null");
+    if (L >= (size_t)1 << 31) return fail(IMC_ERR_ARG, "chunk too long (limit 2^31-1 columns per chunk)");
     std::vector<uint8_t> tmp(L);
     for (size_t t = 0; t < L; ++t) {
         if (sym[t] < 0 || sym[t] >= nsym)
@@ -818,6 +752,7 @@ int imc_obs_create_from_text(const char *path, int nsym, imc_obs **out)
         if (cur >= nsym) return fail(IMC_ERR_SYMBOL, "symbol " + std::to_string(cur) + " >= nsym");
         sym.push_back((uint8_t)cur);
     }
+    if (sym.size() >= (size_t)1 << 31) return fail(IMC_ERR_ARG, "chunk too long (limit 2^31-1 columns per chunk)");
     std::lock_guard<std::mutex> lk(g_mu);
     return obs_upload(sym.data(), sym.size(), nsym, out);
 }
@@ -825,20 +760,32 @@ int imc_obs_create_from_text(const char *path, int nsym, imc_obs **out)
 size_t imc_obs_length(const imc_obs *obs) { return obs ? obs->L : 0; }
 int imc_obs_nsym(const imc_obs *obs) { return obs ? obs->nsym : 0; }
 
+size_t imc_obs_compressed_length(const imc_obs *obs, int alphabet_limit, int *alphabet_used)
+{
+    if (!obs) return 0;
+    size_t n = obs->L;
+    int used = obs->nsym;
+    if (obs->dict)
+        for (int l = 0; l < imc::kNumLevels; ++l)
+            if (obs->alphabet[l] <= alphabet_limit && obs->alphabet[l] > obs->nsym && obs->d_tok[l]) { n = obs->ntok[l]; used = obs->alphabet[l]; }
+    if (alphabet_used) *alphabet_used = used;
+    return n;
+}
+
 int imc_obs_free(imc_obs *obs)
 {
     if (!obs) return IMC_OK;
     std::lock_guard<std::mutex> lk(g_mu);
     if (obs->pid == getpid() && g.ready) {
-        // plans hold raw pointers into this chunk's device buffer
+        // plans hold raw pointers into this chunk's device buffers
         for (auto it = g_plans.begin(); it != g_plans.end();) {
             bool uses = false;
-            for (size_t k = 0; k + 4 <= (*it)->key.size() && k < (size_t)(*it)->n_chunks; ++k)
+            for (size_t k = 0; k < (size_t)(*it)->n_chunks; ++k)
                 if ((*it)->key[k] == obs->id) uses = true;
             if (uses) { (*it)->release(); it = g_plans.erase(it); } else ++it;
         }
         (void)hipSetDevice(obs->device);
-        (void)hipFree(obs->d_sym);
+        obs_release(obs);
     }
     delete obs;
     return IMC_OK;
@@ -891,6 +838,21 @@ int imc_set_segment_length(size_t columns)
     return IMC_OK;
 }
 
+int imc_set_compression(int mode)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (mode != 0 && mode != 1) return fail(IMC_ERR_ARG, "compression mode must be 0 (off) or 1 (auto)");
+    g.compression = mode;
+    return IMC_OK;
+}
+
+int imc_dictionary_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g.dicts.clear();   // chunks already created keep (and share) the dictionary they were encoded with
+    return IMC_OK;
+}
+
 int imc_profile_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -919,13 +881,11 @@ int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propag
     return IMC_OK;
 }
 
-int imc_last_plan(uint64_t *n_segments, uint64_t *n_vectors, uint64_t *segment_len, uint64_t *vector_columns)
+int imc_last_plan(uint64_t *out8)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (n_segments) *n_segments = g.last_segments;
-    if (n_vectors) *n_vectors = g.last_vectors;
-    if (segment_len) *segment_len = g.last_seglen;
-    if (vector_columns) *vector_columns = g.last_vcols;
+    if (!out8) return fail(IMC_ERR_ARG, "out8 is null");
+    for (int k = 0; k < 8; ++k) out8[k] = g.last_plan[k];
     return IMC_OK;
 }
 

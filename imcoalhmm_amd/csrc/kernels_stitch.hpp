@@ -1,0 +1,167 @@
+// kernels_stitch.hpp - combine the per-segment results of the propagate kernels into per-chunk
+// log-likelihoods.  Included by imcoal_fwd.hip only.
+//
+// A level is a list of segments per chunk; a chunk's first segment is a VECTOR (N values + one
+// exponent), every later one an OPERATOR (N x NP block stored state-major [i][c], one exponent per
+// column c).  k_chain folds a run of g consecutive segments into one segment of the next level: a
+// run that starts the chunk yields a vector (one chain), any other run yields an operator (N chains,
+// one per basis vector).  Applied with g ~ sqrt(K) until every chunk holds a single vector, the
+// serial depth drops from K steps to ~2 sqrt(K).  k_finish turns the last vectors into log-likelihoods.
+#pragma once
+#include "kernels_plain.hpp"
+
+struct ChainDesc {
+    uint32_t seg_begin, seg_end;   // input segments [begin, end) of the previous level
+    uint32_t c;                    // basis index when the run does not start its chunk
+    uint32_t out_vec;              // output vector index in the next level
+    uint32_t first;                // 1: the run starts with its chunk's first segment (a vector)
+    uint32_t pad;
+};
+
+// EMAX[b][seg] = max_c EX[b][vec0(seg)+c]
+__global__ void k_emax(const uint32_t *seg_vec0, const uint8_t *seg_first, uint32_t n_segs, uint32_t n_vecs, int N,
+                       const int *EX, int *EMAX)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (s >= n_segs) return;
+    const int *e = EX + (size_t)b * n_vecs + seg_vec0[s];
+    int m = e[0];
+    if (!seg_first[s])
+        for (int c = 1; c < N; ++c) m = max(m, e[c]);
+    EMAX[(size_t)b * n_segs + s] = m;
+}
+
+// One workgroup per (chain, parameter set); thread i owns state i:
+//     a <- Op_k * (a .* 2^(ex_k - emax_k))      for k in the run, rescaled by exact powers of two.
+// With PF the next operator's row and exponents are prefetched into registers during the current step.
+template <int NP, bool PF>
+__global__ __launch_bounds__(((NP + 63) / 64) * 64) void k_chain(
+    const ChainDesc *chains, int N,
+    const uint32_t *in_vec0, uint32_t in_n_segs, uint32_t in_n_vecs, const double *Pin, const int *EXin, const int *EMin,
+    uint32_t out_n_vecs, double *Pout, int *EXout)
+{
+    __shared__ __attribute__((aligned(16))) double w[2][NP];
+    // a single-wavefront workgroup needs no s_barrier (LDS is in-order within a wavefront), and a
+    // __syncthreads() would drain the prefetch loads with its vmcnt(0)
+    constexpr bool ONE_WAVE = NP <= 64;
+    auto sync = [&]() { if (ONE_WAVE) wave_fence(); else __syncthreads(); };
+    const ChainDesc cd = chains[blockIdx.x];
+    const int b = blockIdx.y, i = threadIdx.x;
+    const double *Pb = Pin + (size_t)b * in_n_vecs * NP;
+    const int *EXb = EXin + (size_t)b * in_n_vecs;
+    const int *EMb = EMin + (size_t)b * in_n_segs;
+    const bool mine = i < N;
+    const int ii = mine ? i : 0;
+
+    double a;
+    int etot;
+    uint32_t k0 = cd.seg_begin;
+    if (cd.first) {
+        const uint32_t v = in_vec0[k0];
+        a = mine ? Pb[(size_t)v * NP + i] : 0.0;
+        etot = EXb[v];
+        ++k0;
+    } else {
+        a = (i == (int)cd.c) ? 1.0 : 0.0;
+        etot = 0;
+    }
+    int buf = 0;
+    double2 pk[PF ? NP / 2 : 1];
+    int exk = 0, emk = 0;
+    auto fetch = [&](uint32_t k) {
+        const uint32_t v0 = in_vec0[k];
+        emk = EMb[k];
+        exk = EXb[v0 + ii] - emk;
+        if (PF) {
+            const double2 *row = reinterpret_cast<const double2 *>(Pb + (size_t)v0 * NP + (size_t)ii * NP);
+#pragma unroll
+            for (int m = 0; m < NP / 2; ++m) pk[PF ? m : 0] = row[m];
+        }
+    };
+    if (k0 < cd.seg_end) fetch(k0);
+    for (uint32_t k = k0; k < cd.seg_end; ++k) {
+        const uint32_t v0 = in_vec0[k];
+        const int em = emk;
+        if (mine) w[buf][i] = ldexp(a, exk);
+        else if (i < NP) w[buf][i] = 0.0;
+        double2 cur[PF ? NP / 2 : 1];
+        if (PF) {
+#pragma unroll
+            for (int m = 0; m < NP / 2; ++m) cur[PF ? m : 0] = pk[PF ? m : 0];
+        }
+        if (k + 1 < cd.seg_end) fetch(k + 1);
+        sync();
+        double acc0 = 0.0, acc1 = 0.0, s0 = 0.0, s1 = 0.0;
+        const double2 *wv = reinterpret_cast<const double2 *>(&w[buf][0]);
+        if (PF) {
+#pragma unroll
+            for (int m = 0; m < NP / 2; ++m) {
+                const double2 wc = wv[m];
+                acc0 = fma(cur[PF ? m : 0].x, wc.x, acc0);
+                acc1 = fma(cur[PF ? m : 0].y, wc.y, acc1);
+                s0 += wc.x;
+                s1 += wc.y;
+            }
+        } else {
+            const double2 *row = reinterpret_cast<const double2 *>(Pb + (size_t)v0 * NP + (size_t)ii * NP);
+            for (int m = 0; m < NP / 2; ++m) {
+                const double2 wc = wv[m], pc = row[m];
+                acc0 = fma(pc.x, wc.x, acc0);
+                acc1 = fma(pc.y, wc.y, acc1);
+                s0 += wc.x;
+                s1 += wc.y;
+            }
+        }
+        const double s = s0 + s1;
+        int e = 0;
+        (void)frexp(s, &e);
+        e = (s > 0.0 && s < INFINITY) ? e : 0;
+        a = mine ? ldexp(acc0 + acc1, -e) : 0.0;
+        etot += em + e;
+        buf ^= 1;   // the next step writes the other buffer: one fence per step suffices
+    }
+    // normalise the result by its total and store it as a segment of the next level
+    sync();
+    if (i < NP) w[0][i] = mine ? a : 0.0;
+    sync();
+    double tot = 0.0;
+    for (int c = 0; c < N; ++c) tot += w[0][c];
+    int e = 0;
+    (void)frexp(tot, &e);
+    e = (tot > 0.0 && tot < INFINITY) ? e : 0;
+    const size_t gv = (size_t)b * out_n_vecs + cd.out_vec;
+    if (mine) {
+        double *dst = cd.first ? Pout + gv * NP + i : Pout + (gv - cd.c) * NP + (size_t)i * NP + cd.c;
+        *dst = ldexp(a, -e);
+    }
+    if (i == 0) EXout[gv] = etot + e;
+}
+
+// out[b][f] = log-likelihood of chunk f from its single remaining vector (0.0 for an empty chunk).
+__global__ void k_finish(const int32_t *final_vec, int n_chunks, int N, int NP, uint32_t n_vecs, const double *P,
+                         const int *EX, double *out)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (f >= n_chunks) return;
+    const int32_t v = final_vec[f];
+    double r = 0.0;
+    if (v >= 0) {
+        const double *p = P + ((size_t)b * n_vecs + v) * NP;
+        double tot = 0.0;
+        for (int c = 0; c < N; ++c) tot += p[c];
+        r = (double)EX[(size_t)b * n_vecs + v] * 0.693147180559945309417232121458 + log(tot);
+    }
+    out[(size_t)b * n_chunks + f] = r;
+}
+
+// partial[b] = sum_f per_chunk[b][f], left to right from 0.0 (likelihood.py:33)
+__global__ void k_sum_chunks(const double *per_chunk, int n_chunks, int B, double *partial)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double t = 0.0;
+    for (int f = 0; f < n_chunks; ++f) t += per_chunk[(size_t)b * n_chunks + f];
+    partial[b] = t;
+}

@@ -62,6 +62,10 @@ int imc_obs_create_i32(const int32_t *sym, size_t L, int nsym, imc_obs **out);  
 int imc_obs_create_from_text(const char *path, int nsym, imc_obs **out);
 size_t imc_obs_length(const imc_obs *obs);
 int imc_obs_nsym(const imc_obs *obs);
+/* Length of the chunk's pair-compressed token stream (the `new_obs` of hmm.py:16) at the deepest
+ * dictionary level whose alphabet is <= alphabet_limit; *alphabet_used gets that alphabet
+ * (`new_nsyms`).  Returns the raw length when the chunk is not compressed. */
+size_t imc_obs_compressed_length(const imc_obs *obs, int alphabet_limit, int *alphabet_used);
 int imc_obs_free(imc_obs *obs);
 
 /* Forward log-likelihood: replaces Forwarder.forward -> ziphmm.zip_forward,
@@ -90,15 +94,25 @@ int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, 
                              double *d_out_partial, void *hip_stream);
 
 /* Tuning / measurement ------------------------------------------------------------------ */
-/* Target segment length in columns for the parallel-in-time split (0 = automatic). */
+/* Target segment length, in stream elements (columns, or tokens on the compressed path), for the
+ * parallel-in-time split (0 = automatic). */
 int imc_set_segment_length(size_t columns);
+/* 1 (default): chunks are pair-compressed at creation and evaluated by the token kernel whenever
+ * the operator table fits LDS for the model's N; 0: always the per-column kernel (also skips the
+ * compression of chunks created while it is 0). */
+int imc_set_compression(int mode);
+/* Forget the per-process pair dictionaries: the next sufficiently long chunk trains a new one.
+ * Chunks that already exist keep the dictionary they were encoded with. */
+int imc_dictionary_reset(void);
 /* Kernel timing with HIP events on the launch stream.  After imc_profile_enable(1) every
  * propagate/stitch launch is bracketed by events; imc_profile_read synchronises, returns the
  * accumulated device milliseconds and launch counts since the last reset, and resets. */
 int imc_profile_enable(int on);
 int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propagate, uint64_t *n_stitch);
-/* Description of the last launch plan (segments, vectors, segment length, executed vector-columns). */
-int imc_last_plan(uint64_t *n_segments, uint64_t *n_vectors, uint64_t *segment_len, uint64_t *vector_columns);
+/* Description of the last launch plan, out8[0..7] = segments, vectors, per-column segment length,
+ * executed vector-columns (per-column kernel), token segment length, executed vector-tokens (token
+ * kernel), tokens in the compressed streams, token alphabet. */
+int imc_last_plan(uint64_t *out8);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,13 @@ def test_full_size_segmentation_invariance_and_spot_check(big, hmm_params, oracl
     finally:
         L.imc_set_segment_length(0)
     assert math.isfinite(a) and rel_err(a, b) < 1e-12, (a, b)
+    # the per-column kernel on the same 1e8 columns (compression off at creation) agrees too
+    try:
+        L.imc_set_compression(0)
+        c = Forwarder.from_array(obs, 3).forward(pi, T, E)
+    finally:
+        L.imc_set_compression(1)
+    assert rel_err(a, c) < 1e-12, (a, c)
     head = obs[:2_000_000]
     got = Forwarder.from_array(head, 3).forward(pi, T, E)
     assert rel_err(got, oracle.forward_scaled(pi, T, E, head)) < 1e-11

@@ -30,9 +30,33 @@ def set_seg(n):
     _capi.check(_capi.lib().imc_set_segment_length(n))
 
 
-def test_config1_example_data_golden(hmm_params, example_pairs, golden_loglik):
+def set_zip(mode, reset=True):
+    L = _capi.lib()
+    _capi.check(L.imc_set_compression(mode))
+    if reset:
+        _capi.check(L.imc_dictionary_reset())
+
+
+@pytest.fixture(params=[0, 1], ids=["percolumn", "compressed"])
+def zipmode(request):
+    """Run a test once on the per-column kernel and once with pair compression enabled."""
+    set_zip(request.param)
+    yield request.param
+    set_zip(1)
+
+
+def compressible(n, seed, nsym=3):
+    rng = np.random.default_rng(seed)
+    p = np.full(nsym, 0.1 / max(nsym - 1, 1)); p[0] = 0.9
+    return rng.choice(nsym, size=n, p=p / p.sum()).astype(np.uint8)
+
+
+def test_config1_example_data_golden(hmm_params, example_pairs, golden_loglik, zipmode):
     """BASELINE config 1 (10 states, examples/example_data.fa) and the other golden cells, N<=20."""
     fw = {k: Forwarder.from_array(v, 3) for k, v in example_pairs.items()}
+    if zipmode:
+        ntok, alpha = fw["hg18__pantro2"].compressed_length()
+        assert alpha > 3 and ntok * 8 < 65255          # the reference's example alignment compresses > 8x
     for key, rec in golden_loglik.items():
         pname, mkey = key.split("|")
         if mkey.startswith("im150"):
@@ -43,7 +67,7 @@ def test_config1_example_data_golden(hmm_params, example_pairs, golden_loglik):
 
 
 @pytest.mark.parametrize("seg", [0, 16, 48, 1000, 4096])
-def test_segmentation_invariance(hmm_params, example_pairs, golden_loglik, seg):
+def test_segmentation_invariance(hmm_params, example_pairs, golden_loglik, seg, zipmode):
     """The parallel-in-time split must not change the answer (exact re-association)."""
     try:
         set_seg(seg)
@@ -83,7 +107,7 @@ def test_alphabet_sizes(oracle, nsym):
     assert abs(got - want) < TOL * max(abs(want), 1.0)
 
 
-def test_ragged_and_empty_chunks_sum(oracle, hmm_params):
+def test_ragged_and_empty_chunks_sum(oracle, hmm_params, zipmode):
     """likelihood.py:33 semantics: each chunk restarts from pi, values summed left to right."""
     pi, T, E = hmm_params("iso20_t0")
     lens = [0, 1, 2, 15, 16, 17, 31, 32, 33, 1000, 4097, 65255, 0, 20000]
@@ -112,11 +136,12 @@ def test_ragged_and_empty_chunks_sum(oracle, hmm_params):
         def build_hidden_markov_model(self, p):
             return pi, T, E
     ll = Likelihood(M(), fw)
-    assert ll(np.array([1.0])) == tot
+    assert ll(np.array([1.0])) == forward_chunks([f.handle for f in fw], pi, T, E)   # same (automatic) split
+    assert rel_err(ll(np.array([1.0])), tot) < 1e-13
     assert ll(np.array([-1.0])) == -math.inf
 
 
-def test_batch_of_parameter_sets(oracle, hmm_params):
+def test_batch_of_parameter_sets(oracle, hmm_params, zipmode):
     keys = ["iso20_t0", "iso20_t1", "iso20_t2", "iso20_t3", "im20_t0", "im20_t1"]
     ps = [hmm_params(k) for k in keys]
     pis = np.stack([p[0] for p in ps]); Ts = np.stack([p[1] for p in ps]); Es = np.stack([p[2] for p in ps])
@@ -147,6 +172,48 @@ def test_text_file_constructor(oracle, hmm_params, example_pairs, tmp_path):
     assert len(Forwarder(str(p2), 3)) == 100
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 8, 10, 12, 16, 20, 23, 24, 28, 32, 37, 40])
+def test_compressed_path_all_kernel_shapes(oracle, n):
+    """Token kernel for every (R,G) shape whose operator table fits LDS, mixed with short chunks that
+    stay on the per-column kernel in the same call, with stitching forced (48-token segments)."""
+    set_zip(1)
+    pi, T, E = synth.random_hmm(n, 3, seed=300 + n, stay=0.97)
+    chunks = [compressible(L, seed=n * 10 + k) for k, L in enumerate((40_000, 5000, 4096, 100, 33_000))]
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    assert fw[0].compressed_length()[0] < 40_000 / 3
+    for seg in (48, 0):
+        try:
+            set_seg(seg)
+            got = forward_chunks_batch([f.handle for f in fw], pi[None], T[None], E[None], per_chunk=True)[0]
+            plan = _capi.last_plan()
+        finally:
+            set_seg(0)
+        assert plan["vector_tokens"] > 0 and plan["vector_columns"] > 0     # both launch groups ran
+        for c, g in zip(chunks, got):
+            want = oracle.forward_scaled(pi, T, E, c)
+            assert rel_err(g, want) < TOL, (n, seg, c.size, g, want)
+
+
+def test_compression_off_uses_percolumn_kernel(oracle, hmm_params):
+    pi, T, E = hmm_params("iso20_t0")
+    obs = synth.sample_alignment(pi, T, E, 100_000, seed=5)
+    try:
+        set_zip(0)
+        f = Forwarder.from_array(obs, 3)
+        a = f.forward(pi, T, E)
+        assert _capi.last_plan()["vector_tokens"] == 0
+        set_zip(1)
+        g = Forwarder.from_array(obs, 3)
+        b = g.forward(pi, T, E)
+        plan = _capi.last_plan()
+        assert plan["vector_tokens"] > 0 and plan["vector_columns"] == 0 and 3 < plan["token_alphabet"] <= 32
+        assert f.forward(pi, T, E) == a                   # a chunk created uncompressed stays per-column
+    finally:
+        set_zip(1)
+    want = oracle.forward_scaled(pi, T, E, obs)
+    assert rel_err(a, want) < TOL and rel_err(b, want) < TOL
+
+
 def test_impossible_sequence_and_nan(hmm_params):
     pi = np.array([0.5, 0.5]); T = np.array([[0.9, 0.1], [0.1, 0.9]])
     E = np.array([[1.0, 0.0], [1.0, 0.0]])
@@ -161,7 +228,7 @@ def test_impossible_sequence_and_nan(hmm_params):
         set_seg(0)
 
 
-def test_underflow_guard_long_rare_symbol_runs(oracle):
+def test_underflow_guard_long_rare_symbol_runs(oracle, zipmode):
     """Long runs of a very unlikely symbol: the power-of-two rescale must keep everything finite."""
     n = 20
     pi, T, E = synth.random_hmm(n, 3, seed=77, stay=0.9995)
