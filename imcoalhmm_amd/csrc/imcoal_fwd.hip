@@ -40,6 +40,7 @@
 #include "kernels_plain.hpp"
 #include "kernels_stitch.hpp"
 #include "kernels_zip.hpp"
+#include "kernels_big.hpp"
 #include "pair_dict.hpp"
 
 namespace {
@@ -230,12 +231,14 @@ using ChainFn = void (*)(const ChainDesc *, int, const uint32_t *, uint32_t, uin
                          const int *, uint32_t, double *, int *);
 
 struct KernelChoice {
-    int R, G, NP, VPW, minw;
+    int R, G, NP, VPW, minw;       // R == 0: large-N GEMM-chain path (kernels_big.hpp), NP = 32 * TR
     void (*plain)(PropArgs);
     void (*zip)(PropArgs);
     size_t (*zip_lds)(int);
     ChainFn chain;
     bool zip_attr_set;
+    void (*big_table)(BigArgs);
+    void (*big_prop)(BigArgs);
 };
 
 template <int R, int G, int MW>
@@ -243,15 +246,24 @@ KernelChoice make_kc()
 {
     constexpr int NP = R * G;
     return KernelChoice{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
-                        k_chain<NP, (NP <= 32)>, false};
+                        k_chain<NP, (NP <= 32)>, false, nullptr, nullptr};
+}
+
+template <int NT>
+KernelChoice make_big()
+{
+    constexpr int NP = 16 * NT;   // NT wavefronts per workgroup
+    return KernelChoice{0, NT, NP, 0, 1, nullptr, nullptr, nullptr, k_chain<NP, false>, false, k_big_table<NT>,
+                        k_big_propagate<NT>};
 }
 
 KernelChoice kChoices[] = {
     make_kc<4, 1, 2>(), make_kc<4, 2, 2>(), make_kc<4, 3, 2>(), make_kc<4, 4, 2>(), make_kc<4, 5, 2>(),
     make_kc<3, 8, 2>(), make_kc<2, 14, 2>(), make_kc<2, 16, 2>(), make_kc<2, 20, 1>(), make_kc<1, 48, 1>(),
     make_kc<1, 56, 1>(), make_kc<1, 64, 1>(),
+    make_big<6>(), make_big<8>(), make_big<10>(), make_big<12>(),
 };
-constexpr int IMC_MAX_N = 64;
+constexpr int IMC_MAX_N = 192;
 
 KernelChoice *choose_kernel(int N)
 {
@@ -263,6 +275,11 @@ KernelChoice *choose_kernel(int N)
 // ---- launch plan ----------------------------------------------------------------------------------
 
 struct Group {             // one propagate launch
+    bool big = false;      // large-N GEMM-chain kernel (one workgroup per segment)
+    std::vector<uint32_t> seg_ids;
+    uint32_t *d_seg_ids = nullptr;
+    double *d_Ctab = nullptr, *d_scratch = nullptr;
+    int *d_cex = nullptr;
     bool zip = false;
     int level = -1, A = 0;
     std::shared_ptr<DictDev> dict;
@@ -305,6 +322,7 @@ struct Plan {
     {
         (void)hipFree(d_segs); (void)hipFree(d_vecs); (void)hipFree(d_final_vec);
         for (auto &l : levels) l.release();
+        for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_scratch); (void)hipFree(gr.d_cex); }
         (void)hipFree(d_params); (void)hipFree(d_out);
         (void)hipHostFree(h_params); (void)hipHostFree(h_out);
     }
@@ -370,9 +388,12 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     p->key = key; p->kc = kc; p->N = N; p->S = S; p->B = B; p->n_chunks = n_chunks;
 
     // ---- assign chunks to launch groups: plain, or (dictionary, level) ----
-    int a_max = 0;   // largest alphabet whose operator table fits LDS for this N
-    for (int A = 1; A <= imc::kMaxAlphabet; ++A)
-        if (kc->zip_lds(A) <= LDS_BUDGET) a_max = A;
+    const bool big = kc->R == 0;
+    int a_max = 0;   // largest alphabet whose operator table fits LDS for this N (no limit on the large-N path)
+    if (big) a_max = imc::kMaxAlphabet;
+    else
+        for (int A = 1; A <= imc::kMaxAlphabet; ++A)
+            if (kc->zip_lds(A) <= LDS_BUDGET) a_max = A;
     std::vector<int> chunk_group(n_chunks, -1);
     for (int f = 0; f < n_chunks; ++f) {
         const imc_obs *o = chunks[f];
@@ -389,6 +410,8 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             Group gr;
             gr.zip = level >= 0;
             gr.level = level;
+            gr.big = big;
+            gr.A = S;
             if (gr.zip) { gr.dict = o->dict; gr.A = o->alphabet[level]; }
             p->groups.push_back(gr);
             gi = (int)p->groups.size() - 1;
@@ -401,7 +424,13 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         std::vector<size_t> lens;
         for (int f : gr.chunks) lens.push_back(gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L);
         if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);
-        else if (gr.zip) {
+        else if (gr.big) {
+            // every non-first segment costs N^3 per step whatever the split: just fill the machine ~4x over
+            size_t total = 0;
+            for (size_t L : lens) total += L;
+            const size_t target = std::max<size_t>(1, (size_t)4 * g.cus / (size_t)B);
+            gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
+        } else if (gr.zip) {
             // LDS-bound: a workgroup of ZWAVES wavefronts serialises on one CU's LDS
             const double lds_cycles = ((double)kc->R * kc->NP / 2 + kc->NP / 2.0) * 4.0 + kc->R * 6.0 + 40.0;
             gr.seglen = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * ZWAVES, lds_cycles * ZWAVES / 4.0);
@@ -436,6 +465,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         for (int f : gr.chunks) {
             gr.stream_len += gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L;
             for (uint32_t sid = chunk_seg[f]; sid < chunk_seg[f + 1]; ++sid) {
+                if (gr.big) gr.seg_ids.push_back(sid);
                 seg_vec0[sid] = (uint32_t)vecs.size();
                 const int nv = seg_first[sid] ? 1 : N;
                 for (int c = 0; c < nv; ++c) vecs.push_back(VecDesc{sid, (uint32_t)c});
@@ -521,6 +551,14 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         if (e == hipSuccess) e = zalloc((void **)&lv.d_EX, (size_t)B * nv * 4);
         if (e == hipSuccess) e = zalloc((void **)&lv.d_EMAX, (size_t)B * ns * 4);
     }
+    for (Group &gr : q->groups) {
+        if (!gr.big || e != hipSuccess) continue;
+        const size_t np2 = (size_t)kc->NP * kc->NP;
+        e = up((void **)&gr.d_seg_ids, gr.seg_ids.data(), gr.seg_ids.size() * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&gr.d_Ctab, (size_t)B * gr.A * np2 * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&gr.d_cex, (size_t)B * gr.A * 4 + 16);
+        if (e == hipSuccess) e = hipMalloc((void **)&gr.d_scratch, (size_t)B * std::max<size_t>(gr.seg_ids.size(), 1) * 2 * np2 * 8);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_params, (size_t)B * q->pstride * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_out, (size_t)B * std::max(n_chunks, 1) * 8);
     if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_params, (size_t)B * q->pstride * 8, hipHostMallocDefault);
@@ -586,7 +624,19 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
         a.n_vecs_total = p->n_vecs; a.N = N; a.S = S;
         a.params = p->d_params; a.pstride = p->pstride; a.P = p->levels[0].d_P; a.EX = p->levels[0].d_EX;
         a.A = gr.A; a.tok_left = gr.zip ? gr.dict->d_left : nullptr; a.tok_right = gr.zip ? gr.dict->d_right : nullptr;
-        if (gr.zip) {
+        if (gr.big) {
+            BigArgs ba;
+            ba.segs = p->d_segs; ba.seg_ids = gr.d_seg_ids; ba.seg_vec0 = p->levels[0].d_vec0;
+            ba.n_group_segs = (uint32_t)gr.seg_ids.size(); ba.n_vecs_total = p->n_vecs;
+            ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
+            ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
+            ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex; ba.scratch = gr.d_scratch;
+            ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
+            hipLaunchKernelGGL(kc->big_table, dim3((unsigned)B), dim3(kc->G * 64), 0, stream, ba);
+            HIP_TRY(hipGetLastError());
+            hipLaunchKernelGGL(kc->big_prop, dim3(ba.n_group_segs, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
+            lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
+        } else if (gr.zip) {
             const size_t lds = kc->zip_lds(gr.A);
             if (!kc->zip_attr_set) {
                 HIP_TRY(hipFuncSetAttribute((const void *)kc->zip, hipFuncAttributeMaxDynamicSharedMemorySize,

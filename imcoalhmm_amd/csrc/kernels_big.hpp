@@ -1,0 +1,223 @@
+// kernels_big.hpp - forward propagate for large state counts (64 < N <= 192).  Included by imcoal_fwd.hip.
+//
+// For N ~ 150 neither the N x N operators (180 KB each) nor a segment's transfer operator fit a CU's
+// LDS or one wavefront's registers, and the work per token step, P <- C_tok * P (N x N by N x N), is a
+// genuine dense fp64 GEMM.  This is the one place where the matrix cores are the right tool
+// ("MFMA becomes relevant only if the N^3 transfer-operator formulation is adopted"):
+// one workgroup owns one segment; with NT = NP/16 tiles per dimension its NT wavefronts form an (NT/2) x 2
+// grid, each computing a 32 x (8 NT) block of P_new as 2 x NT/2 accumulator tiles of
+// v_mfma_f64_16x16x4_f64 (<= 12 tiles = 96 accumulator registers, so 2-3 wavefronts fit per SIMD).  The A
+// fragments (rows of C_tok) and B fragments (rows of P_old) are loaded straight from L1/L2-resident global
+// memory into registers; neither LDS nor HBM is a limit.
+// P ping-pongs between two global scratch buffers of the workgroup; every step is rescaled by one exact
+// power of two (the exponent of the largest entry).
+#pragma once
+#include "kernels_plain.hpp"
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+struct BigArgs {
+    const SegDesc *segs;          // all segments of the plan
+    const uint32_t *seg_ids;      // segments of this launch group
+    const uint32_t *seg_vec0;     // plan-wide: first vector index of a segment
+    uint32_t n_group_segs;
+    uint32_t n_vecs_total;
+    int N, S, A;
+    const double *params;         // per parameter set: pi[PP] | Tp[PP*PP] | Et[S*PP]   (PP = params' padding)
+    size_t pstride;
+    int PP;
+    const uint8_t *tok_left, *tok_right;
+    double *Ctab;                 // [B][A][NP][NP] operator table (row-major, zero padded)
+    int *cex;                     // [B][A] power-of-two exponents of the table entries
+    double *scratch;              // [B][n_group_segs][2][NP][NP]
+    double *P;                    // level-0 results (see kernels_stitch.hpp for the layout)
+    int *EX;
+};
+
+
+// acc[tr][tc] += A(rows row0.., all k) * B(all k, cols col0..) for one workgroup-wide GEMM of size NP.
+// A and B are row-major NP x NP in global memory.  k is consumed in blocks of 16: lane l takes
+// k = kb*16 + 4*(l>>4) + s for s = 0..3 from both operands (any common order of k is a valid sum).
+template <int NT>
+__device__ __forceinline__ void big_gemm(const double *__restrict__ A, const double *__restrict__ B, int row0, int col0,
+                                         int lane, v4f64 (&acc)[2][NT / 2])
+{
+    constexpr int NP = 16 * NT, TR = 2, TC = NT / 2;
+    const int lm = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) acc[tr][tc] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int kb = 0; kb < NP / 16; ++kb) {
+        double a[TR][4], bq[TC][4];
+#pragma unroll
+        for (int tr = 0; tr < TR; ++tr) {
+            const double2 *ap = reinterpret_cast<const double2 *>(A + (size_t)(row0 + tr * 16 + lm) * NP + kb * 16 + 4 * lg);
+            const double2 a01 = ap[0], a23 = ap[1];
+            a[tr][0] = a01.x; a[tr][1] = a01.y; a[tr][2] = a23.x; a[tr][3] = a23.y;
+        }
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bq[tc][s] = B[(size_t)(kb * 16 + 4 * lg + s) * NP + col0 + tc * 16 + lm];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc)
+                    acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr][s], bq[tc][s], acc[tr][tc], 0, 0, 0);
+    }
+}
+
+// Workgroup-wide maximum of the (non-negative) accumulator entries -> exponent e with max in [2^(e-1), 2^e).
+// smax: two LDS slots used alternately (slot `which`); the other slot is cleared for the next call.
+template <int NT>
+__device__ __forceinline__ int big_exponent(const v4f64 (&acc)[2][NT / 2], unsigned long long *smax, int which, int tid)
+{
+    constexpr int TR = 2, TC = NT / 2;
+    double mx = 0.0;
+#pragma unroll
+    for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = acc[tr][tc][q];
+                mx = (v > mx || v != v) ? v : mx;
+            }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double o = __shfl_xor(mx, m, 64);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    if ((tid & 63) == 0) atomicMax(&smax[which], (unsigned long long)__double_as_longlong(mx));
+    __syncthreads();
+    const double m = __longlong_as_double((long long)smax[which]);
+    if (tid == 0) smax[which ^ 1] = 0ull;
+    int e = 0;
+    (void)frexp(m, &e);
+    return (m > 0.0 && m < INFINITY) ? e : 0;
+}
+
+// Store the scaled accumulator tiles: D layout of v_mfma_f64_16x16x4_f64 is row = (lane>>4) + 4*reg, col = lane&15.
+template <int NT>
+__device__ __forceinline__ void big_store(double *__restrict__ D, int row0, int col0, int lane, const v4f64 (&acc)[2][NT / 2],
+                                          int e, int row_limit, int col_limit, size_t ld)
+{
+    constexpr int TR = 2, TC = NT / 2;
+    const int lm = lane & 15, lg = lane >> 4;
+#pragma unroll
+    for (int tr = 0; tr < TR; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = row0 + tr * 16 + lg + 4 * q, col = col0 + tc * 16 + lm;
+                if (row < row_limit && col < col_limit) D[(size_t)row * ld + col] = ldexp(acc[tr][tc][q], -e);
+            }
+}
+
+// Operator table for one parameter set: raw symbols C_s[i][j] = E[i][s] T[j][i], merged tokens
+// C_z = C_right * C_left (left is applied first), each normalised by a power of two.  One workgroup per
+// parameter set walks the dictionary in order (a token only depends on earlier ones).
+template <int NT>
+__global__ __launch_bounds__(NT * 64) void k_big_table(BigArgs a)
+{
+    constexpr int NP = 16 * NT, BIG_THREADS = NT * 64;
+    __shared__ unsigned long long smax[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const double *pp = a.params + (size_t)b * a.pstride;
+    const double *Tp = pp + a.PP;
+    const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
+    double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
+    int *cex = a.cex + (size_t)b * a.A;
+    for (int idx = tid; idx < a.S * NP * NP; idx += BIG_THREADS) {
+        const int s = idx / (NP * NP);
+        const int rem = idx - s * NP * NP;
+        const int i = rem / NP, j = rem - i * NP;
+        Ct[idx] = (i < a.N && j < a.N) ? Etg[(size_t)s * a.PP + i] * Tp[(size_t)j * a.PP + i] : 0.0;
+    }
+    if (tid < a.S) cex[tid] = 0;
+    if (tid < 2) smax[tid] = 0ull;
+    __threadfence_block();
+    __syncthreads();
+    const int row0 = (wave >> 1) * 32, col0 = (wave & 1) * 8 * NT;
+    for (int z = a.S; z < a.A; ++z) {
+        const int zl = a.tok_left[z], zr = a.tok_right[z];
+        v4f64 acc[2][NT / 2];
+        big_gemm<NT>(Ct + (size_t)zr * NP * NP, Ct + (size_t)zl * NP * NP, row0, col0, lane, acc);
+        const int e = big_exponent<NT>(acc, smax, z & 1, tid);
+        big_store<NT>(Ct + (size_t)z * NP * NP, row0, col0, lane, acc, e, NP, NP, NP);
+        if (tid == 0) cex[z] = cex[zl] + cex[zr] + e;
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// One workgroup per (segment, parameter set): P <- C_tok * P over the segment's tokens.
+template <int NT>
+__global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a)
+{
+    constexpr int NP = 16 * NT, BIG_THREADS = NT * 64;
+    __shared__ unsigned long long smax[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const uint32_t seg = a.seg_ids[blockIdx.x];
+    const SegDesc sd = a.segs[seg];
+    const bool first = sd.first != 0;
+    const int len = (int)sd.len;
+    const uint8_t *tokp = sd.obs;
+    const double *pp = a.params + (size_t)b * a.pstride;
+    const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
+    const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
+    const int *cex = a.cex + (size_t)b * a.A;
+    double *buf0 = a.scratch + ((size_t)b * a.n_group_segs + blockIdx.x) * 2 * NP * NP;
+    double *buf1 = buf0 + (size_t)NP * NP;
+
+    // initial P: identity, or (first segment) column 0 = pi .* E[:,o_0] and nothing else
+    const int tok0 = first ? (int)tokp[0] : 0;
+    for (int idx = tid; idx < NP * NP; idx += BIG_THREADS) {
+        const int i = idx / NP, j = idx - i * NP;
+        double v;
+        if (first) v = (j == 0 && i < a.N) ? pp[i] * Etg[(size_t)tok0 * a.PP + i] : 0.0;
+        else v = (i == j && i < a.N) ? 1.0 : 0.0;
+        buf0[idx] = v;
+    }
+    if (tid < 2) smax[tid] = 0ull;
+    __threadfence_block();
+    __syncthreads();
+
+    const int row0 = (wave >> 1) * 32, col0 = (wave & 1) * 8 * NT;
+    long long ex = 0;
+    double *cur = buf0, *nxt = buf1;
+    v4f64 acc[2][NT / 2];
+    int which = 0;
+    for (int t = first ? 1 : 0; t < len; ++t) {
+        const int tok = tokp[t];
+        big_gemm<NT>(Ct + (size_t)tok * NP * NP, cur, row0, col0, lane, acc);
+        const int e = big_exponent<NT>(acc, smax, which, tid);
+        which ^= 1;
+        big_store<NT>(nxt, row0, col0, lane, acc, e, NP, NP, NP);
+        ex += cex[tok] + e;
+        __threadfence_block();
+        __syncthreads();
+        double *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    // results -> level 0: operator block state-major [i][c] (N x PP0) or, for a first segment, the vector [i]
+    const uint32_t v0 = a.seg_vec0[seg];
+    const size_t gv = (size_t)b * a.n_vecs_total + v0;
+    double *Pout = a.P + gv * NP;
+    if (first) {
+        for (int i = tid; i < a.N; i += BIG_THREADS) Pout[i] = cur[(size_t)i * NP];
+        if (tid == 0) a.EX[gv] = (int)ex;
+    } else {
+        for (int idx = tid; idx < a.N * NP; idx += BIG_THREADS) {
+            const int i = idx / NP, c = idx - i * NP;
+            Pout[idx] = (c < a.N) ? cur[(size_t)i * NP + c] : 0.0;
+        }
+        for (int c = tid; c < a.N; c += BIG_THREADS) a.EX[gv + c] = (int)ex;
+    }
+}
