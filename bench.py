@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--states", type=int, default=20)
+    ap.add_argument("--fixture", type=str, default="",
+                    help="(pi,T,E) fixture key in tests/golden/hmm_params.npz, e.g. im150_t0 (default iso<states>_t0)")
     ap.add_argument("--columns", type=int, default=0, help="override columns per chunk")
     ap.add_argument("--chunks", type=int, default=0, help="override chunks per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -65,7 +67,7 @@ def main():
 
     # ---- workload -------------------------------------------------------------------------------
     d = np.load(os.path.join(REPO, "tests", "golden", "hmm_params.npz"))
-    key = "iso%d_t0" % args.states
+    key = args.fixture or "iso%d_t0" % args.states
     if key + "_pi" not in d.files:
         raise SystemExit("no (pi,T,E) fixture for %d states" % args.states)
     pi, T, E = d[key + "_pi"], d[key + "_T"], d[key + "_E"]
@@ -73,8 +75,9 @@ def main():
     if world == 1:
         chunks_per_rank = args.chunks or 1
         cols = args.columns or 100_000_000
-        workload = "isolation-model %d states, %d x %d-column synthetic pairwise alignment (BASELINE config[1])" % (
-            n_states, chunks_per_rank, cols)
+        workload = "%s %d states, %d x %d-column synthetic pairwise alignment (BASELINE config[%d])" % (
+            "isolation-model" if key.startswith("iso") else "initial-migration-model", n_states, chunks_per_rank, cols,
+            1 if key.startswith("iso") else 2)
         seeds = [20240001 + k for k in range(chunks_per_rank)]
     else:
         chunks_per_rank = args.chunks or 32
@@ -149,7 +152,8 @@ def main():
         alg_flops = float(local_cols) * (2 * n_states * n_states + 3 * n_states)
         exe_flops = (float(plan["vector_columns"]) * (2 * n_states * n_states + 3 * n_states)
                      + float(plan["vector_tokens"]) * (2 * n_states * n_states))
-        kernel_name = "k_zpropagate (token kernel)" if plan["vector_tokens"] else "k_propagate (per-column kernel)"
+        kernel_name = ("k_big_propagate (fp64 MFMA GEMM chain)" if n_states > 64 else
+                       "k_zpropagate (token kernel)" if plan["vector_tokens"] else "k_propagate (per-column kernel)")
         achieved_gbs = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
         out = {
             "metric": "alignment columns/sec (forward pass), %d-state isolation HMM" % n_states,
