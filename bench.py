@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--no-compress", action="store_true",
                     help="per-column kernel only (skip the pair-compressed token path)")
     ap.add_argument("--cpu-sample-columns", type=int, default=4_000_000, help="columns per CPU thread")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a 1-GPU box: every rank uses device 0 and the reduction runs "
+                         "over gloo (RCCL refuses two ranks on one device); never used for reported numbers")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -56,14 +59,18 @@ def main():
     from imcoalhmm_amd import Forwarder, _capi, synth
     from imcoalhmm_amd.dist import DistributedLikelihood, shard_indices
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.rehearse_on_one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     lib = _capi.lib()                       # raises if the HIP library is missing (no fallback)
-    _capi.check(lib.imc_set_device(local_rank))
+    _capi.check(lib.imc_set_device(dev_index))
     _capi.check(lib.imc_set_compression(0 if args.no_compress else 1))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ---- workload -------------------------------------------------------------------------------
     d = np.load(os.path.join(REPO, "tests", "golden", "hmm_params.npz"))
@@ -107,7 +114,7 @@ def main():
         def build_hidden_markov_model(self, p):
             return pi, T, E
 
-    ll = DistributedLikelihood(FixedModel(), forwarders, device=dev)
+    ll = DistributedLikelihood(FixedModel(), forwarders, device=dev, reduce_on_host=args.rehearse_on_one_gpu)
 
     def step():
         return ll.forward_params(pi, T, E)
@@ -135,10 +142,11 @@ def main():
     ntok0, alpha0 = forwarders[0].compressed_length(plan["token_alphabet"] or 128) if plan["vector_tokens"] else (len(forwarders[0]), 3)
 
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([float(local_cols)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(local_cols)], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_cols = float(tot.item())
     else:

@@ -41,6 +41,7 @@
 #include "kernels_stitch.hpp"
 #include "kernels_zip.hpp"
 #include "kernels_big.hpp"
+#include "kernels_zip2.hpp"
 #include "pair_dict.hpp"
 
 namespace {
@@ -239,14 +240,22 @@ struct KernelChoice {
     bool zip_attr_set;
     void (*big_table)(BigArgs);
     void (*big_prop)(BigArgs);
+    void (*zip2)(BigArgs);         // register-blocked token kernel (NP = 4 RB <= 24), else null
+    size_t (*zip2_lds)(int);
+    bool zip2_attr_set;
 };
 
 template <int R, int G, int MW>
 KernelChoice make_kc()
 {
     constexpr int NP = R * G;
-    return KernelChoice{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
-                        k_chain<NP, (NP <= 32)>, false, nullptr, nullptr};
+    KernelChoice k{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
+                   k_chain<NP, (NP <= 32)>, false, nullptr, nullptr, nullptr, nullptr, false};
+    if constexpr (NP % 4 == 0 && NP <= 24) {
+        k.zip2 = k_zpropagate2<NP / 4>;
+        k.zip2_lds = &Zip2Geom<NP / 4>::lds_bytes;
+    }
+    return k;
 }
 
 template <int NT>
@@ -254,7 +263,7 @@ KernelChoice make_big()
 {
     constexpr int NP = 16 * NT;   // NT wavefronts per workgroup
     return KernelChoice{0, NT, NP, 0, 1, nullptr, nullptr, nullptr, k_chain<NP, false>, false, k_big_table<NT>,
-                        k_big_propagate<NT>};
+                        k_big_propagate<NT>, nullptr, nullptr, false};
 }
 
 KernelChoice kChoices[] = {
@@ -276,6 +285,7 @@ KernelChoice *choose_kernel(int N)
 
 struct Group {             // one propagate launch
     bool big = false;      // large-N GEMM-chain kernel (one workgroup per segment)
+    bool zip2 = false;     // register-blocked token kernel (one 16-lane row per segment)
     std::vector<uint32_t> seg_ids;
     uint32_t *d_seg_ids = nullptr;
     double *d_Ctab = nullptr, *d_scratch = nullptr;
@@ -430,6 +440,17 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             for (size_t L : lens) total += L;
             const size_t target = std::max<size_t>(1, (size_t)4 * g.cus / (size_t)B);
             gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
+        } else if (gr.zip && kc->zip2 && g.compression != 2 && kc->zip2_lds(gr.A) <= LDS_BUDGET &&
+                   [&] {   // operators must dominate first-segment vectors, or the blocked kernel idles 15/16 lanes
+                       size_t total = 0;
+                       for (size_t L : lens) total += L;
+                       const size_t target = std::max<size_t>(1, (size_t)g.cus * Z2WAVES * 4 / (size_t)B);
+                       gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
+                       size_t k = 0;
+                       for (size_t L : lens) k += (L + gr.seglen - 1) / gr.seglen;
+                       return g.compression == 3 || k >= 16 * lens.size();
+                   }()) {
+            gr.zip2 = true;   // gr.seglen set above
         } else if (gr.zip) {
             // LDS-bound: a workgroup of ZWAVES wavefronts serialises on one CU's LDS
             const double lds_cycles = ((double)kc->R * kc->NP / 2 + kc->NP / 2.0) * 4.0 + kc->R * 6.0 + 40.0;
@@ -465,7 +486,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         for (int f : gr.chunks) {
             gr.stream_len += gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L;
             for (uint32_t sid = chunk_seg[f]; sid < chunk_seg[f + 1]; ++sid) {
-                if (gr.big) gr.seg_ids.push_back(sid);
+                if (gr.big || gr.zip2) gr.seg_ids.push_back(sid);
                 seg_vec0[sid] = (uint32_t)vecs.size();
                 const int nv = seg_first[sid] ? 1 : N;
                 for (int c = 0; c < nv; ++c) vecs.push_back(VecDesc{sid, (uint32_t)c});
@@ -552,6 +573,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         if (e == hipSuccess) e = zalloc((void **)&lv.d_EMAX, (size_t)B * ns * 4);
     }
     for (Group &gr : q->groups) {
+        if (gr.zip2 && e == hipSuccess) e = up((void **)&gr.d_seg_ids, gr.seg_ids.data(), gr.seg_ids.size() * 4);
         if (!gr.big || e != hipSuccess) continue;
         const size_t np2 = (size_t)kc->NP * kc->NP;
         e = up((void **)&gr.d_seg_ids, gr.seg_ids.data(), gr.seg_ids.size() * 4);
@@ -635,6 +657,23 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
             hipLaunchKernelGGL(kc->big_table, dim3((unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(kc->big_prop, dim3(ba.n_group_segs, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
+            lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
+        } else if (gr.zip2) {
+            BigArgs ba;
+            ba.segs = p->d_segs; ba.seg_ids = gr.d_seg_ids; ba.seg_vec0 = p->levels[0].d_vec0;
+            ba.n_group_segs = (uint32_t)gr.seg_ids.size(); ba.n_vecs_total = p->n_vecs;
+            ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
+            ba.tok_left = gr.dict->d_left; ba.tok_right = gr.dict->d_right;
+            ba.Ctab = nullptr; ba.cex = nullptr; ba.scratch = nullptr;
+            ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
+            if (!kc->zip2_attr_set) {
+                HIP_TRY(hipFuncSetAttribute((const void *)kc->zip2, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)LDS_BUDGET));
+                kc->zip2_attr_set = true;
+            }
+            const uint32_t spb = Z2WAVES * 4;
+            hipLaunchKernelGGL(kc->zip2, dim3((ba.n_group_segs + spb - 1) / spb, (unsigned)B), dim3(Z2WAVES * 64),
+                               kc->zip2_lds(gr.A), stream, ba);
             lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
         } else if (gr.zip) {
             const size_t lds = kc->zip_lds(gr.A);
@@ -891,7 +930,8 @@ int imc_set_segment_length(size_t columns)
 int imc_set_compression(int mode)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (mode != 0 && mode != 1) return fail(IMC_ERR_ARG, "compression mode must be 0 (off) or 1 (auto)");
+    if (mode < 0 || mode > 3)
+        return fail(IMC_ERR_ARG, "compression mode must be 0 (off), 1 (auto), 2 (vector token kernel) or 3 (blocked token kernel)");
     g.compression = mode;
     return IMC_OK;
 }

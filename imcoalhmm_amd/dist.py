@@ -25,7 +25,7 @@ class DistributedLikelihood(object):
     and RCCL reduces it in place.
     """
 
-    def __init__(self, model, local_forwarders, group=None, device=None, local_eval=None):
+    def __init__(self, model, local_forwarders, group=None, device=None, local_eval=None, reduce_on_host=False):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -37,6 +37,7 @@ class DistributedLikelihood(object):
         self.group = group
         self.device = device
         self._local_eval = local_eval or self._hip_eval
+        self.reduce_on_host = reduce_on_host     # gloo rehearsals: reduce a host copy of the partial sums
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def _hip_eval(self, pis, Ts, Es):
@@ -56,6 +57,8 @@ class DistributedLikelihood(object):
         """Global log-likelihoods (float64[B]) for B parameter sets; collective over the group."""
         pis, Ts, Es = hmm._batch_params(pis, Ts, Es)
         partial = self._local_eval(pis, Ts, Es)
+        if self.reduce_on_host:
+            partial = partial.cpu()
         if self.world_size > 1:
             self._dist.all_reduce(partial, op=self._dist.ReduceOp.SUM, group=self.group)
         return partial.detach().cpu().numpy()

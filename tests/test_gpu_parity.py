@@ -37,9 +37,9 @@ def set_zip(mode, reset=True):
         _capi.check(L.imc_dictionary_reset())
 
 
-@pytest.fixture(params=[0, 1], ids=["percolumn", "compressed"])
+@pytest.fixture(params=[0, 2, 3, 1], ids=["percolumn", "token-vector", "token-blocked", "auto"])
 def zipmode(request):
-    """Run a test once on the per-column kernel and once with pair compression enabled."""
+    """Run a test on the per-column kernel, on each pinned token-kernel variant and with automatic choice."""
     set_zip(request.param)
     yield request.param
     set_zip(1)
@@ -172,10 +172,12 @@ def test_text_file_constructor(oracle, hmm_params, example_pairs, tmp_path):
 
 
 @pytest.mark.parametrize("n", [1, 3, 4, 8, 10, 12, 16, 20, 23, 24, 28, 32, 37, 40, 70, 150])
-def test_compressed_path_all_kernel_shapes(oracle, n):
-    """Token kernel for every (R,G) shape whose operator table fits LDS, mixed with short chunks that
-    stay on the per-column kernel in the same call, with stitching forced (48-token segments)."""
-    set_zip(1)
+@pytest.mark.parametrize("mode", [2, 3], ids=["token-vector", "token-blocked"])
+def test_compressed_path_all_kernel_shapes(oracle, n, mode):
+    """Both token kernels for every shape whose operator table fits LDS (mode 3 falls back to the vector
+    variant above N=24), mixed with short chunks that stay on the per-column kernel in the same call,
+    with stitching forced (48-token segments)."""
+    set_zip(mode)
     pi, T, E = synth.random_hmm(n, 3, seed=300 + n, stay=0.97)
     chunks = [compressible(L, seed=n * 10 + k) for k, L in enumerate((40_000, 5000, 4096, 100, 33_000))]
     fw = [Forwarder.from_array(c, 3) for c in chunks]
@@ -192,6 +194,7 @@ def test_compressed_path_all_kernel_shapes(oracle, n):
         for c, g in zip(chunks, got):
             want = oracle.forward_scaled(pi, T, E, c)
             assert rel_err(g, want) < TOL, (n, seg, c.size, g, want)
+    set_zip(1)
 
 
 def test_compression_off_uses_percolumn_kernel(oracle, hmm_params):
