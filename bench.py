@@ -161,8 +161,18 @@ def main():
         exe_flops = (float(plan["vector_columns"]) * (2 * n_states * n_states + 3 * n_states)
                      + float(plan["vector_tokens"]) * (2 * n_states * n_states))
         kernel_name = ("k_big_propagate (fp64 MFMA GEMM chain)" if n_states > 64 else
-                       "k_zpropagate (token kernel)" if plan["vector_tokens"] else "k_propagate (per-column kernel)")
+                       ("k_zpropagate2 (register-blocked token kernel)" if plan["token_segment_len"] and plan["vectors"] > 100000 else "k_zpropagate (token kernel)") if plan["vector_tokens"] else "k_propagate (per-column kernel)")
         achieved_gbs = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
+        # HBM traffic per launch comes from PMC passes (rocprofv3 cannot run inside the bench): the committed
+        # measurement for this kernel / N / column count, if any (profiles/r01_traffic_pmc.json), else null
+        traffic = None
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_traffic_pmc.json")) as fh:
+                rec = json.load(fh).get("%s|%d|%d" % (kernel_name.split(" ")[0], n_states, local_cols))
+            if rec and world == 1:
+                traffic = rec["hbm_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "alignment columns/sec (forward pass), %d-state isolation HMM" % n_states,
             "value": cols_per_s,
@@ -185,7 +195,7 @@ def main():
                        "setup_s": t_setup, "loglik": value},
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": kernel_name, "kernel_ms": k_ms, "stitch_ms": ms_s.value / max(n_s.value, 1),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "north_star names the HBM roof, but with 1 B/column the path is fp64-VALU/latency bound; "
