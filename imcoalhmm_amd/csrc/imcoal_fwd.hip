@@ -250,7 +250,7 @@ KernelChoice make_kc()
 {
     constexpr int NP = R * G;
     KernelChoice k{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
-                   k_chain<NP, (NP <= 32)>, false, nullptr, nullptr, nullptr, nullptr, false};
+                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, nullptr, false};
     if constexpr (NP % 4 == 0 && NP <= 24) {
         k.zip2 = k_zpropagate2<NP / 4>;
         k.zip2_lds = &Zip2Geom<NP / 4>::lds_bytes;
@@ -262,7 +262,7 @@ template <int NT>
 KernelChoice make_big()
 {
     constexpr int NP = 16 * NT;   // NT wavefronts per workgroup
-    return KernelChoice{0, NT, NP, 0, 1, nullptr, nullptr, nullptr, k_chain<NP, false>, false, k_big_table<NT>,
+    return KernelChoice{0, NT, NP, 0, 1, nullptr, nullptr, nullptr, k_chain<NP, 0>, false, k_big_table<NT>,
                         k_big_propagate<NT>, nullptr, nullptr, false};
 }
 
@@ -511,7 +511,8 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         // a level whose chunks all hold one first-vector is final; level 0 operators always need one pass
         if (kmax <= 1 && hl.size() > 1) break;
         if (kmax == 0) break;
-        const uint32_t gsz = kmax <= 12 ? kmax : (uint32_t)std::ceil(std::sqrt((double)kmax));
+        // ~3 levels: per level a chain costs g serial steps (~0.3 us each) plus two launches (~6 us)
+        const uint32_t gsz = kmax <= 16 ? kmax : std::max<uint32_t>(12, (uint32_t)std::ceil(std::cbrt((double)kmax)));
         p->chain_steps += gsz;
         HostLevel nx;
         nx.chunk_seg.assign(n_chunks + 1, 0);

@@ -34,8 +34,10 @@ __global__ void k_emax(const uint32_t *seg_vec0, const uint8_t *seg_first, uint3
 
 // One workgroup per (chain, parameter set); thread i owns state i:
 //     a <- Op_k * (a .* 2^(ex_k - emax_k))      for k in the run, rescaled by exact powers of two.
-// With PF the next operator's row and exponents are prefetched into registers during the current step.
-template <int NP, bool PF>
+// The operators of a run are consecutive N-vector blocks, so their addresses are known up front: the
+// rows and exponents of the next D operators are kept in flight in a register ring (D-deep prefetch),
+// which takes the L2/HBM latency (~0.7 us) off the serial chain.
+template <int NP, int D>
 __global__ __launch_bounds__(((NP + 63) / 64) * 64) void k_chain(
     const ChainDesc *chains, int N,
     const uint32_t *in_vec0, uint32_t in_n_segs, uint32_t in_n_vecs, const double *Pin, const int *EXin, const int *EMin,
@@ -66,45 +68,23 @@ __global__ __launch_bounds__(((NP + 63) / 64) * 64) void k_chain(
         a = (i == (int)cd.c) ? 1.0 : 0.0;
         etot = 0;
     }
-    int buf = 0;
-    double2 pk[PF ? NP / 2 : 1];
-    int exk = 0, emk = 0;
-    auto fetch = [&](uint32_t k) {
-        const uint32_t v0 = in_vec0[k];
-        emk = EMb[k];
-        exk = EXb[v0 + ii] - emk;
-        if (PF) {
-            const double2 *row = reinterpret_cast<const double2 *>(Pb + (size_t)v0 * NP + (size_t)ii * NP);
-#pragma unroll
-            for (int m = 0; m < NP / 2; ++m) pk[PF ? m : 0] = row[m];
-        }
-    };
-    if (k0 < cd.seg_end) fetch(k0);
-    for (uint32_t k = k0; k < cd.seg_end; ++k) {
-        const uint32_t v0 = in_vec0[k];
-        const int em = emk;
-        if (mine) w[buf][i] = ldexp(a, exk);
-        else if (i < NP) w[buf][i] = 0.0;
-        double2 cur[PF ? NP / 2 : 1];
-        if (PF) {
-#pragma unroll
-            for (int m = 0; m < NP / 2; ++m) cur[PF ? m : 0] = pk[PF ? m : 0];
-        }
-        if (k + 1 < cd.seg_end) fetch(k + 1);
-        sync();
-        double acc0 = 0.0, acc1 = 0.0, s0 = 0.0, s1 = 0.0;
-        const double2 *wv = reinterpret_cast<const double2 *>(&w[buf][0]);
-        if (PF) {
-#pragma unroll
-            for (int m = 0; m < NP / 2; ++m) {
-                const double2 wc = wv[m];
-                acc0 = fma(cur[PF ? m : 0].x, wc.x, acc0);
-                acc1 = fma(cur[PF ? m : 0].y, wc.y, acc1);
-                s0 += wc.x;
-                s1 += wc.y;
-            }
-        } else {
-            const double2 *row = reinterpret_cast<const double2 *>(Pb + (size_t)v0 * NP + (size_t)ii * NP);
+    const int nsteps = (int)cd.seg_end - (int)k0;
+    // operator k0+t starts at vector vbase + t*N (every segment after a chunk's first is an operator)
+    const uint32_t vbase = nsteps > 0 ? in_vec0[k0] : 0u;
+
+    if constexpr (D == 0) {
+        // large NP: no register ring (it would not fit); stream the operator row straight from L2
+        int buf = 0;
+        for (int t = 0; t < nsteps; ++t) {
+            const size_t v0 = (size_t)vbase + (size_t)t * N;
+            const int em = EMb[k0 + t];
+            if (mine) w[buf][i] = ldexp(a, EXb[v0 + ii] - em);
+            else if (i < NP) w[buf][i] = 0.0;
+            sync();
+            const double2 *row = reinterpret_cast<const double2 *>(Pb + (v0 + ii) * NP);
+            const double2 *wv = reinterpret_cast<const double2 *>(&w[buf][0]);
+            double acc0 = 0.0, acc1 = 0.0, s0 = 0.0, s1 = 0.0;
+#pragma unroll 4
             for (int m = 0; m < NP / 2; ++m) {
                 const double2 wc = wv[m], pc = row[m];
                 acc0 = fma(pc.x, wc.x, acc0);
@@ -112,14 +92,62 @@ __global__ __launch_bounds__(((NP + 63) / 64) * 64) void k_chain(
                 s0 += wc.x;
                 s1 += wc.y;
             }
+            const double sm = s0 + s1;
+            int e = 0;
+            (void)frexp(sm, &e);
+            e = (sm > 0.0 && sm < INFINITY) ? e : 0;
+            a = mine ? ldexp(acc0 + acc1, -e) : 0.0;
+            etot += em + e;
+            buf ^= 1;
         }
-        const double s = s0 + s1;
-        int e = 0;
-        (void)frexp(s, &e);
-        e = (s > 0.0 && s < INFINITY) ? e : 0;
-        a = mine ? ldexp(acc0 + acc1, -e) : 0.0;
-        etot += em + e;
-        buf ^= 1;   // the next step writes the other buffer: one fence per step suffices
+    } else {
+    double2 pk[D > 0 ? D : 1][NP / 2];
+    int exr[D > 0 ? D : 1], emr[D > 0 ? D : 1];
+    auto fetch = [&](int t, int slot) {   // slot is a compile-time constant at every call site
+        const size_t v0 = (size_t)vbase + (size_t)t * N;
+        emr[slot] = EMb[k0 + t];
+        exr[slot] = EXb[v0 + ii];
+        const double2 *row = reinterpret_cast<const double2 *>(Pb + (v0 + ii) * NP);
+#pragma unroll
+        for (int m = 0; m < NP / 2; ++m) pk[slot][m] = row[m];
+    };
+#pragma unroll
+    for (int s = 0; s < D; ++s)
+        if (s < nsteps) fetch(s, s);   // (D > 0 here)
+    int buf = 0;
+    for (int t0 = 0; t0 < nsteps; t0 += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int t = t0 + s;
+            if (t < nsteps) {   // wave-uniform
+                const int em = emr[s];
+                if (mine) w[buf][i] = ldexp(a, exr[s] - em);
+                else if (i < NP) w[buf][i] = 0.0;
+                double2 cur[NP / 2];
+#pragma unroll
+                for (int m = 0; m < NP / 2; ++m) cur[m] = pk[s][m];
+                if (t + D < nsteps) fetch(t + D, s);
+                sync();
+                double acc0 = 0.0, acc1 = 0.0, s0 = 0.0, s1 = 0.0;
+                const double2 *wv = reinterpret_cast<const double2 *>(&w[buf][0]);
+#pragma unroll
+                for (int m = 0; m < NP / 2; ++m) {
+                    const double2 wc = wv[m];
+                    acc0 = fma(cur[m].x, wc.x, acc0);
+                    acc1 = fma(cur[m].y, wc.y, acc1);
+                    s0 += wc.x;
+                    s1 += wc.y;
+                }
+                const double sm = s0 + s1;
+                int e = 0;
+                (void)frexp(sm, &e);
+                e = (sm > 0.0 && sm < INFINITY) ? e : 0;
+                a = mine ? ldexp(acc0 + acc1, -e) : 0.0;
+                etot += em + e;
+                buf ^= 1;   // the next step writes the other buffer: one fence per step suffices
+            }
+        }
+    }
     }
     // normalise the result by its total and store it as a segment of the next level
     sync();
