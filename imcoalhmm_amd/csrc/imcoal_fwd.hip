@@ -83,7 +83,8 @@ struct Ctx {
     int cus = 256;
     uint64_t next_obs_id = 1, next_dict_id = 1;
     size_t seg_override = 0;
-    int compression = 1;      // 0 = plain per-column kernel only, 1 = automatic
+    int compression = 1;      // 0 = raw symbol stream, 1 = pair-compressed token stream where possible
+    int kernel_pref = 0;      // 0 = automatic, 1 = vector kernels (k_propagate / k_zpropagate), 2 = blocked (k_zpropagate2)
     bool profile = false;
     std::vector<Ev3> events;
     std::map<int, std::shared_ptr<DictDev>> dicts;   // by raw alphabet size
@@ -384,7 +385,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     key.reserve(n_chunks + 5);
     for (int f = 0; f < n_chunks; ++f) key.push_back(chunks[f]->id);
     key.push_back((uint64_t)N); key.push_back((uint64_t)S); key.push_back((uint64_t)B);
-    key.push_back((uint64_t)g.seg_override); key.push_back((uint64_t)g.compression);
+    key.push_back((uint64_t)g.seg_override); key.push_back((uint64_t)(g.compression * 4 + g.kernel_pref));
     for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
         if ((*it)->key == key) {
             g_plans.splice(g_plans.begin(), g_plans, it);
@@ -440,7 +441,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             for (size_t L : lens) total += L;
             const size_t target = std::max<size_t>(1, (size_t)4 * g.cus / (size_t)B);
             gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
-        } else if (gr.zip && kc->zip2 && g.compression != 2 && kc->zip2_lds(gr.A) <= LDS_BUDGET &&
+        } else if (kc->zip2 && g.kernel_pref != 1 && kc->zip2_lds(gr.A) <= LDS_BUDGET && (gr.zip || S == gr.A) &&
                    [&] {   // operators must dominate first-segment vectors, or the blocked kernel idles 15/16 lanes
                        size_t total = 0;
                        for (size_t L : lens) total += L;
@@ -448,7 +449,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
                        gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
                        size_t k = 0;
                        for (size_t L : lens) k += (L + gr.seglen - 1) / gr.seglen;
-                       return g.compression == 3 || k >= 16 * lens.size();
+                       return g.kernel_pref == 2 || k >= 16 * lens.size();
                    }()) {
             gr.zip2 = true;   // gr.seglen set above
         } else if (gr.zip) {
@@ -664,7 +665,7 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
             ba.segs = p->d_segs; ba.seg_ids = gr.d_seg_ids; ba.seg_vec0 = p->levels[0].d_vec0;
             ba.n_group_segs = (uint32_t)gr.seg_ids.size(); ba.n_vecs_total = p->n_vecs;
             ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
-            ba.tok_left = gr.dict->d_left; ba.tok_right = gr.dict->d_right;
+            ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
             ba.Ctab = nullptr; ba.cex = nullptr; ba.scratch = nullptr;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
             if (!kc->zip2_attr_set) {
@@ -675,7 +676,8 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
             const uint32_t spb = Z2WAVES * 4;
             hipLaunchKernelGGL(kc->zip2, dim3((ba.n_group_segs + spb - 1) / spb, (unsigned)B), dim3(Z2WAVES * 64),
                                kc->zip2_lds(gr.A), stream, ba);
-            lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
+            if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A; }
+            else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }
         } else if (gr.zip) {
             const size_t lds = kc->zip_lds(gr.A);
             if (!kc->zip_attr_set) {
@@ -931,9 +933,9 @@ int imc_set_segment_length(size_t columns)
 int imc_set_compression(int mode)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (mode < 0 || mode > 3)
-        return fail(IMC_ERR_ARG, "compression mode must be 0 (off), 1 (auto), 2 (vector token kernel) or 3 (blocked token kernel)");
-    g.compression = mode;
+    if (mode < 0 || mode > 5) return fail(IMC_ERR_ARG, "compression mode must be in [0,5]");
+    g.compression = (mode == 1 || mode == 2 || mode == 3) ? 1 : 0;
+    g.kernel_pref = (mode == 2 || mode == 4) ? 1 : (mode == 3 || mode == 5) ? 2 : 0;
     return IMC_OK;
 }
 

@@ -97,11 +97,14 @@ int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, 
 /* Target segment length, in stream elements (columns, or tokens on the compressed path), for the
  * parallel-in-time split (0 = automatic). */
 int imc_set_segment_length(size_t columns);
-/* 1 (default): chunks are pair-compressed at creation and evaluated by the token kernel whenever
- * the operator table fits LDS for the model's N; 0: always the per-column kernel (also skips the
- * compression of chunks created while it is 0).  2 / 3 pin the token kernel variant (2: one vector per
- * lane group, k_zpropagate; 3: register-blocked operator per 16-lane row, k_zpropagate2) where 1
- * chooses between them from the segment/chunk ratio. */
+/* Stream and kernel selection.
+ *   1 (default): chunks are pair-compressed at creation and evaluated from the token stream whenever the
+ *      operator table fits LDS for the model's N; the kernel variant is chosen from the segment/chunk ratio.
+ *   0: raw symbol stream only (also skips the compression of chunks created while it is 0); kernel chosen
+ *      automatically.
+ *   2 / 3: as 1 but pin the kernel: 2 = one vector per lane group (k_zpropagate), 3 = register-blocked
+ *      operator per 16-lane row (k_zpropagate2, N <= 24).
+ *   4 / 5: as 0 but pin the kernel: 4 = k_propagate (T' in registers, LDS broadcast), 5 = k_zpropagate2. */
 int imc_set_compression(int mode);
 /* Forget the per-process pair dictionaries: the next sufficiently long chunk trains a new one.
  * Chunks that already exist keep the dictionary they were encoded with. */

@@ -37,7 +37,7 @@ def set_zip(mode, reset=True):
         _capi.check(L.imc_dictionary_reset())
 
 
-@pytest.fixture(params=[0, 2, 3, 1], ids=["percolumn", "token-vector", "token-blocked", "auto"])
+@pytest.fixture(params=[4, 5, 0, 2, 3, 1], ids=["raw-vector", "raw-blocked", "raw-auto", "token-vector", "token-blocked", "auto"])
 def zipmode(request):
     """Run a test on the per-column kernel, on each pinned token-kernel variant and with automatic choice."""
     set_zip(request.param)
@@ -54,7 +54,7 @@ def compressible(n, seed, nsym=3):
 def test_config1_example_data_golden(hmm_params, example_pairs, golden_loglik, zipmode):
     """BASELINE config 1 (10 states, examples/example_data.fa) and the other golden cells, N<=20."""
     fw = {k: Forwarder.from_array(v, 3) for k, v in example_pairs.items()}
-    if zipmode:
+    if zipmode in (1, 2, 3):
         ntok, alpha = fw["hg18__pantro2"].compressed_length()
         assert alpha > 3 and ntok * 8 < 65255          # the reference's example alignment compresses > 8x
     for key, rec in golden_loglik.items():
@@ -190,7 +190,7 @@ def test_compressed_path_all_kernel_shapes(oracle, n, mode):
         finally:
             set_seg(0)
         assert plan["vector_tokens"] > 0                                      # the token path ran
-        assert n > 64 or plan["vector_columns"] > 0                           # ... and so did the per-column group
+        assert n > 64 or plan["vector_columns"] > 0                           # ... and so did the raw-stream group
         for c, g in zip(chunks, got):
             want = oracle.forward_scaled(pi, T, E, c)
             assert rel_err(g, want) < TOL, (n, seg, c.size, g, want)
