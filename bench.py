@@ -161,17 +161,14 @@ def main():
         alg_flops = float(local_cols) * (2 * n_states * n_states + 3 * n_states)
         exe_flops = (float(plan["vector_columns"]) * (2 * n_states * n_states + 3 * n_states)
                      + float(plan["vector_tokens"]) * (2 * n_states * n_states))
-        blocked = plan["vectors"] > 20 * plan["segments"] * 0 and (plan["token_segment_len"] or plan["column_segment_len"]) and plan["segments"] >= 4096
-        kernel_name = ("k_big_propagate (fp64 MFMA GEMM chain)" if n_states > 64 else
-                       "k_zpropagate2 (register-blocked kernel, raw symbol stream)" if blocked and not plan["vector_tokens"] else
-                       ("k_zpropagate2 (register-blocked token kernel)" if plan["token_segment_len"] and plan["vectors"] > 100000 else "k_zpropagate (token kernel)") if plan["vector_tokens"] else "k_propagate (per-column kernel)")
+        kernel_name = plan["kernels"]
         achieved_gbs = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
         # HBM traffic per launch comes from PMC passes (rocprofv3 cannot run inside the bench): the committed
         # measurement for this kernel / N / column count, if any (profiles/r01_traffic_pmc.json), else null
         traffic = None
         try:
             with open(os.path.join(REPO, "profiles", "r01_traffic_pmc.json")) as fh:
-                rec = json.load(fh).get("%s|%d|%d" % (kernel_name.split(" ")[0], n_states, local_cols))
+                rec = json.load(fh).get("%s|%d|%d" % (kernel_name, n_states, local_cols))
             if rec and world == 1:
                 traffic = rec["hbm_bytes_per_launch"]
         except (OSError, ValueError):

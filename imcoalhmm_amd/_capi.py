@@ -53,6 +53,7 @@ SIGNATURES = [
     ("imc_profile_enable", ctypes.c_int, [ctypes.c_int]),
     ("imc_profile_read", ctypes.c_int, [_dp, _dp, _u64p, _u64p]),
     ("imc_last_plan", ctypes.c_int, [_u64p]),
+    ("imc_last_kernels", ctypes.c_char_p, []),
 ]
 
 _lib = None
@@ -118,4 +119,6 @@ def last_plan():
     check(lib().imc_last_plan(arr))
     keys = ("segments", "vectors", "column_segment_len", "vector_columns", "token_segment_len",
             "vector_tokens", "tokens", "token_alphabet")
-    return dict(zip(keys, [int(x) for x in arr]))
+    d = dict(zip(keys, [int(x) for x in arr]))
+    d["kernels"] = lib().imc_last_kernels().decode()
+    return d

@@ -89,6 +89,7 @@ struct Ctx {
     std::vector<Ev3> events;
     std::map<int, std::shared_ptr<DictDev>> dicts;   // by raw alphabet size
     uint64_t last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::string last_kernels;   // propagate kernels of the last enqueue, e.g. "k_zpropagate2<5>[tokens]"
 } g;
 
 void drop_plans();
@@ -287,8 +288,10 @@ KernelChoice *choose_kernel(int N)
 struct Group {             // one propagate launch
     bool big = false;      // large-N GEMM-chain kernel (one workgroup per segment)
     bool zip2 = false;     // register-blocked token kernel (one 16-lane row per segment)
-    std::vector<uint32_t> seg_ids;
-    uint32_t *d_seg_ids = nullptr;
+    std::vector<uint32_t> seg_ids, seg_out;   // big: segment ids and their level-0 vector index
+    std::vector<Z2Block> blocks;              // zip2: one entry per workgroup
+    uint32_t *d_seg_ids = nullptr, *d_seg_out = nullptr;
+    Z2Block *d_blocks = nullptr;
     double *d_Ctab = nullptr, *d_scratch = nullptr;
     int *d_cex = nullptr;
     bool zip = false;
@@ -333,7 +336,7 @@ struct Plan {
     {
         (void)hipFree(d_segs); (void)hipFree(d_vecs); (void)hipFree(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_scratch); (void)hipFree(gr.d_cex); }
+        for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_seg_out); (void)hipFree(gr.d_blocks); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_scratch); (void)hipFree(gr.d_cex); }
         (void)hipFree(d_params); (void)hipFree(d_out);
         (void)hipHostFree(h_params); (void)hipHostFree(h_out);
     }
@@ -479,19 +482,37 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         }
     }
     chunk_seg[n_chunks] = (uint32_t)segs.size();
-    // ---- vectors, contiguous per group ----
+    // ---- stitch units and their vectors, contiguous per group ----
+    // A unit is what the stitch hierarchy sees at level 0: a segment, or (blocked kernel) a workgroup's
+    // run of up to 32 consecutive segments of one chunk, already folded inside the kernel.
     std::vector<VecDesc> vecs;
-    std::vector<uint32_t> seg_vec0(segs.size(), 0);
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> chunk_units(n_chunks);   // per chunk: (seg0, nsegs)
+    for (int f = 0; f < n_chunks; ++f) {
+        const Group &gr = p->groups[chunk_group[f]];
+        const uint32_t step = gr.zip2 ? 32u : 1u;
+        for (uint32_t sid = chunk_seg[f]; sid < chunk_seg[f + 1]; sid += step)
+            chunk_units[f].push_back({sid, std::min(step, chunk_seg[f + 1] - sid)});
+    }
+    std::vector<uint32_t> chunk_unit(n_chunks + 1, 0);
+    for (int f = 0; f < n_chunks; ++f) chunk_unit[f + 1] = chunk_unit[f] + (uint32_t)chunk_units[f].size();
+    std::vector<uint32_t> unit_vec0(chunk_unit[n_chunks], 0);
+    std::vector<uint8_t> unit_first(chunk_unit[n_chunks], 0);
     for (Group &gr : p->groups) {
         gr.vec_begin = (uint32_t)vecs.size();
         for (int f : gr.chunks) {
             gr.stream_len += gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L;
-            for (uint32_t sid = chunk_seg[f]; sid < chunk_seg[f + 1]; ++sid) {
-                if (gr.big || gr.zip2) gr.seg_ids.push_back(sid);
-                seg_vec0[sid] = (uint32_t)vecs.size();
-                const int nv = seg_first[sid] ? 1 : N;
+            for (size_t u = 0; u < chunk_units[f].size(); ++u) {
+                const uint32_t sid = chunk_units[f][u].first, ns = chunk_units[f][u].second;
+                const uint32_t uid = chunk_unit[f] + (uint32_t)u;
+                const bool fst = seg_first[sid] != 0;
+                unit_first[uid] = fst;
+                unit_vec0[uid] = (uint32_t)vecs.size();
+                const int nv = fst ? 1 : N;
                 for (int c = 0; c < nv; ++c) vecs.push_back(VecDesc{sid, (uint32_t)c});
-                gr.vsteps += (uint64_t)nv * segs[sid].len;
+                if (gr.big) { gr.seg_ids.push_back(sid); gr.seg_out.push_back(unit_vec0[uid]); }
+                if (gr.zip2) gr.blocks.push_back(Z2Block{sid, ns, unit_vec0[uid], fst ? 1u : 0u});
+                for (uint32_t q2 = 0; q2 < ns; ++q2)
+                    gr.vsteps += (uint64_t)((seg_first[sid + q2] && !gr.zip2) ? 1 : N) * segs[sid + q2].len;
             }
         }
         gr.n_vecs = (uint32_t)vecs.size() - gr.vec_begin;
@@ -504,7 +525,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     // ---- stitch hierarchy: fold runs of g ~ sqrt(K) consecutive segments until one vector per chunk ----
     struct HostLevel { std::vector<uint32_t> chunk_seg, vec0; std::vector<uint8_t> first; std::vector<ChainDesc> chains; uint32_t n_vecs; };
     std::vector<HostLevel> hl(1);
-    hl[0].chunk_seg = chunk_seg; hl[0].vec0 = seg_vec0; hl[0].first = seg_first; hl[0].n_vecs = p->n_vecs;
+    hl[0].chunk_seg = chunk_unit; hl[0].vec0 = unit_vec0; hl[0].first = unit_first; hl[0].n_vecs = p->n_vecs;
     for (;;) {
         const HostLevel &cur = hl.back();
         uint32_t kmax = 0;
@@ -575,10 +596,11 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         if (e == hipSuccess) e = zalloc((void **)&lv.d_EMAX, (size_t)B * ns * 4);
     }
     for (Group &gr : q->groups) {
-        if (gr.zip2 && e == hipSuccess) e = up((void **)&gr.d_seg_ids, gr.seg_ids.data(), gr.seg_ids.size() * 4);
+        if (gr.zip2 && e == hipSuccess) e = up((void **)&gr.d_blocks, gr.blocks.data(), gr.blocks.size() * sizeof(Z2Block));
         if (!gr.big || e != hipSuccess) continue;
         const size_t np2 = (size_t)kc->NP * kc->NP;
         e = up((void **)&gr.d_seg_ids, gr.seg_ids.data(), gr.seg_ids.size() * 4);
+        if (e == hipSuccess) e = up((void **)&gr.d_seg_out, gr.seg_out.data(), gr.seg_out.size() * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&gr.d_Ctab, (size_t)B * gr.A * np2 * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&gr.d_cex, (size_t)B * gr.A * 4 + 16);
         if (e == hipSuccess) e = hipMalloc((void **)&gr.d_scratch, (size_t)B * std::max<size_t>(gr.seg_ids.size(), 1) * 2 * np2 * 8);
@@ -641,8 +663,11 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
         HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); HIP_TRY(hipEventCreate(&ev.c));
         HIP_TRY(hipEventRecord(ev.a, stream));
     }
+    g.last_kernels.clear();
+    auto note = [&](const std::string &k) { g.last_kernels += (g.last_kernels.empty() ? "" : "+") + k; };
     for (const Group &gr : p->groups) {
         if (!gr.n_vecs) continue;
+        const std::string strm = gr.zip ? "[tokens]" : "[columns]";
         PropArgs a;
         a.segs = p->d_segs; a.vecs = p->d_vecs + gr.vec_begin; a.n_vecs = gr.n_vecs; a.vec_base = gr.vec_begin;
         a.n_vecs_total = p->n_vecs; a.N = N; a.S = S;
@@ -650,7 +675,7 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
         a.A = gr.A; a.tok_left = gr.zip ? gr.dict->d_left : nullptr; a.tok_right = gr.zip ? gr.dict->d_right : nullptr;
         if (gr.big) {
             BigArgs ba;
-            ba.segs = p->d_segs; ba.seg_ids = gr.d_seg_ids; ba.seg_vec0 = p->levels[0].d_vec0;
+            ba.segs = p->d_segs; ba.seg_ids = gr.d_seg_ids; ba.seg_vec0 = gr.d_seg_out; ba.blocks = nullptr;
             ba.n_group_segs = (uint32_t)gr.seg_ids.size(); ba.n_vecs_total = p->n_vecs;
             ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
@@ -659,11 +684,12 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
             hipLaunchKernelGGL(kc->big_table, dim3((unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
             hipLaunchKernelGGL(kc->big_prop, dim3(ba.n_group_segs, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
+            note("k_big_propagate<" + std::to_string(kc->G) + ">" + strm);
             lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
         } else if (gr.zip2) {
             BigArgs ba;
-            ba.segs = p->d_segs; ba.seg_ids = gr.d_seg_ids; ba.seg_vec0 = p->levels[0].d_vec0;
-            ba.n_group_segs = (uint32_t)gr.seg_ids.size(); ba.n_vecs_total = p->n_vecs;
+            ba.segs = p->d_segs; ba.seg_ids = nullptr; ba.seg_vec0 = nullptr; ba.blocks = gr.d_blocks;
+            ba.n_group_segs = (uint32_t)gr.blocks.size(); ba.n_vecs_total = p->n_vecs;
             ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
             ba.Ctab = nullptr; ba.cex = nullptr; ba.scratch = nullptr;
@@ -673,9 +699,9 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
                                             (int)LDS_BUDGET));
                 kc->zip2_attr_set = true;
             }
-            const uint32_t spb = Z2WAVES * 4;
-            hipLaunchKernelGGL(kc->zip2, dim3((ba.n_group_segs + spb - 1) / spb, (unsigned)B), dim3(Z2WAVES * 64),
+            hipLaunchKernelGGL(kc->zip2, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64),
                                kc->zip2_lds(gr.A), stream, ba);
+            note("k_zpropagate2<" + std::to_string(NP / 4) + ">" + strm);
             if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A; }
             else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }
         } else if (gr.zip) {
@@ -688,12 +714,14 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
             const uint32_t vpb = (uint32_t)(ZWAVES * kc->VPW);
             dim3 grid((gr.n_vecs + vpb - 1) / vpb, (unsigned)B);
             hipLaunchKernelGGL(kc->zip, grid, dim3(ZWAVES * 64), lds, stream, a);
+            note("k_zpropagate<" + std::to_string(kc->R) + "," + std::to_string(kc->G) + ">" + strm);
             lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
         } else {
             const uint32_t vpb = (uint32_t)(WPB * kc->VPW);
             dim3 grid((gr.n_vecs + vpb - 1) / vpb, (unsigned)B);
             const size_t lds = ((size_t)WPB * kc->VPW * NP + (size_t)S * NP) * 8;
             hipLaunchKernelGGL(kc->plain, grid, dim3(WPB * 64), lds, stream, a);
+            note("k_propagate<" + std::to_string(kc->R) + "," + std::to_string(kc->G) + ">" + strm);
             lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B;
         }
         HIP_TRY(hipGetLastError());
@@ -972,6 +1000,14 @@ int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propag
     if (n_stitch) *n_stitch = g.events.size();
     g.events.clear();
     return IMC_OK;
+}
+
+const char *imc_last_kernels(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    static thread_local std::string copy;
+    copy = g.last_kernels;
+    return copy.c_str();
 }
 
 int imc_last_plan(uint64_t *out8)

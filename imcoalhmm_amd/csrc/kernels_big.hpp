@@ -16,10 +16,17 @@
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+struct Z2Block {                  // one workgroup of k_zpropagate2: up to 32 consecutive segments of one chunk
+    uint32_t seg0, n;             // first segment id, number of segments
+    uint32_t out_vec0;            // where the block's combined result goes (level-0 vector index)
+    uint32_t first;               // 1: seg0 is its chunk's first segment -> the result is a vector
+};
+
 struct BigArgs {
     const SegDesc *segs;          // all segments of the plan
-    const uint32_t *seg_ids;      // segments of this launch group
-    const uint32_t *seg_vec0;     // plan-wide: first vector index of a segment
+    const uint32_t *seg_ids;      // k_big_propagate: segments of this launch group
+    const uint32_t *seg_vec0;     // k_big_propagate: level-0 vector index per entry of seg_ids
+    const Z2Block *blocks;        // k_zpropagate2: one entry per workgroup
     uint32_t n_group_segs;
     uint32_t n_vecs_total;
     int N, S, A;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a)
         double *tmp = cur; cur = nxt; nxt = tmp;
     }
     // results -> level 0: operator block state-major [i][c] (N x PP0) or, for a first segment, the vector [i]
-    const uint32_t v0 = a.seg_vec0[seg];
+    const uint32_t v0 = a.seg_vec0[blockIdx.x];
     const size_t gv = (size_t)b * a.n_vecs_total + v0;
     double *Pout = a.P + gv * NP;
     if (first) {

@@ -37,7 +37,9 @@ template <int RB>
 struct Zip2Geom {
     static constexpr int NP = 4 * RB;
     static constexpr int NPS = NP + 2;   // operator row stride in LDS (doubles): rows of one grid column land on distinct banks
-    static constexpr size_t lds_bytes(int A) { return ((size_t)A * NP * NPS) * 8 + (size_t)((A + 1) & ~1) * 4 + 16; }
+    // the operator table doubles as the exchange area of the end-of-kernel fold (32 slots)
+    static constexpr int slots(int A) { return A > 32 ? A : 32; }
+    static constexpr size_t lds_bytes(int A) { return ((size_t)slots(A) * NP * NPS) * 8 + (size_t)((slots(A) + 1) & ~1) * 4 + 16; }
 };
 
 // acc[ii][cc] += sum_jj C[row0+ii][j0+jj] * src[jj][cc]
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(Z2WAVES * 64, 2) void k_zpropagate2(BigArgs a)
     constexpr int EPT = (NP * NP + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *C = lds;                                                   // [A][NP][NPS]
-    int *cex = reinterpret_cast<int *>(C + (size_t)a.A * NP * NPS);    // [A]
-    unsigned long long *smax = reinterpret_cast<unsigned long long *>(cex + ((a.A + 1) & ~1));   // [2]
+    int *cex = reinterpret_cast<int *>(C + (size_t)Geo::slots(a.A) * NP * NPS);    // [slots]
+    unsigned long long *smax = reinterpret_cast<unsigned long long *>(cex + ((Geo::slots(a.A) + 1) & ~1));   // [2]
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -199,9 +201,10 @@ __global__ __launch_bounds__(Z2WAVES * 64, 2) void k_zpropagate2(BigArgs a)
     const int lane = tid & 63;
     const int q16 = lane & 15, rb = q16 >> 2, cb = q16 & 3;
     const int rbs[3] = {dpp_i32<DPP_ROW_ROR4>(rb), dpp_i32<DPP_ROW_ROR8>(rb), dpp_i32<DPP_ROW_ROR12>(rb)};
-    const uint32_t slot = (blockIdx.x * Z2WAVES + (tid >> 6)) * 4 + (lane >> 4);
-    const bool valid = slot < a.n_group_segs;
-    const uint32_t seg = a.seg_ids[min(slot, a.n_group_segs - 1u)];
+    const Z2Block blk = a.blocks[blockIdx.x];
+    const int slot = (tid >> 6) * 4 + (lane >> 4);          // 0..31 within the workgroup
+    const bool valid = slot < (int)blk.n;
+    const uint32_t seg = blk.seg0 + (valid ? slot : 0);
     const SegDesc sd = a.segs[seg];
     const int len = valid ? (int)sd.len : 0;
     const bool first = sd.first != 0;
@@ -223,9 +226,7 @@ __global__ __launch_bounds__(Z2WAVES * 64, 2) void k_zpropagate2(BigArgs a)
     }
     int ex = 0;
     const int maxlen = wave_max_i32(len);
-    const int nfull = wave_min_i32(valid ? len / RESCALE_EVERY : INT_MAX);
-    if (maxlen == 0) return;
-
+    const int nfull = maxlen == 0 ? 0 : wave_min_i32(valid ? len / RESCALE_EVERY : INT_MAX);   // idle wavefronts still join the fold's barriers
     const int head_end = min(RESCALE_EVERY, maxlen);
     for (int t = 0; t < head_end; ++t) {
         const bool act = t < len && !(first && t == 0);   // token 0 of a first segment went into the initial P
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(Z2WAVES * 64, 2) void k_zpropagate2(BigArgs a)
         zip2_step<RB, true>(P, C, cex, act ? tok : 0, rb, rbs, act, ex);
     }
     zip2_rescale<RB>(P, ex);
-    for (int blk = 1; blk < nfull; ++blk) {
-        const uint4 ob = *reinterpret_cast<const uint4 *>(tokp + (size_t)blk * RESCALE_EVERY);
+    for (int bi = 1; bi < nfull; ++bi) {
+        const uint4 ob = *reinterpret_cast<const uint4 *>(tokp + (size_t)bi * RESCALE_EVERY);
         uint32_t w0 = ob.x, w1 = ob.y, w2 = ob.z, w3 = ob.w;
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
@@ -254,11 +255,30 @@ __global__ __launch_bounds__(Z2WAVES * 64, 2) void k_zpropagate2(BigArgs a)
     }
     zip2_rescale<RB>(P, ex);
 
-    if (valid) {
-        const uint32_t v0 = a.seg_vec0[seg];
-        const size_t gv = (size_t)b * a.n_vecs_total + v0;
+    // ---- fold the workgroup's segments into one: P_0 <- P_{n-1} ... P_1 P_0 (binary tree through LDS) ----
+    // The operator table is dead once every wavefront is here; its space becomes the exchange area, and a
+    // fold step is an ordinary token step whose "token operator" is the partner slot's P.
+    for (int stride = 1; stride < 32; stride <<= 1) {
+        if ((int)blk.n <= stride) break;          // workgroup-uniform
+        __syncthreads();                          // table (or previous level's exchange data) no longer read
+        if (valid && (slot & stride) && !(slot & (stride - 1))) {   // this slot is a partner ("hi") at this level
+            double *dst = C + (size_t)slot * (NP * NPS) + (size_t)(rb * RB) * NPS + cb * RB;
+#pragma unroll
+            for (int ii = 0; ii < RB; ++ii)
+#pragma unroll
+                for (int cc = 0; cc < RB; ++cc) dst[ii * NPS + cc] = P[ii][cc];
+            if (q16 == 0) cex[slot] = ex;
+        }
+        __syncthreads();
+        const bool act = valid && !(slot & (2 * stride - 1)) && slot + stride < (int)blk.n;
+        zip2_step<RB, true>(P, C, cex, act ? slot + stride : 0, rb, rbs, act, ex);
+        zip2_rescale<RB>(P, ex);
+    }
+
+    if (slot == 0) {
+        const size_t gv = (size_t)b * a.n_vecs_total + blk.out_vec0;
         double *Pout = a.P + gv * NP;
-        if (first) {
+        if (blk.first) {
             if (cb == 0) {
 #pragma unroll
                 for (int ii = 0; ii < RB; ++ii)

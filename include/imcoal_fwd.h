@@ -118,6 +118,8 @@ int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propag
  * executed vector-columns (per-column kernel), token segment length, executed vector-tokens (token
  * kernel), tokens in the compressed streams, token alphabet. */
 int imc_last_plan(uint64_t *out8);
+/* Propagate kernels launched by the last forward call, '+'-joined, e.g. "k_zpropagate2<5>[tokens]". */
+const char *imc_last_kernels(void);
 
 #ifdef __cplusplus
 }
