@@ -38,6 +38,8 @@ def main():
                     help="(pi,T,E) fixture key in tests/golden/hmm_params.npz, e.g. im150_t0 (default iso<states>_t0)")
     ap.add_argument("--columns", type=int, default=0, help="override columns per chunk")
     ap.add_argument("--chunks", type=int, default=0, help="override chunks per rank")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="parameter sets evaluated per step (BASELINE config[4] uses 64 proposals/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-compress", action="store_true",
                     help="raw symbol stream (one step per alignment column), kernel chosen automatically")
@@ -117,7 +119,17 @@ def main():
 
     ll = DistributedLikelihood(FixedModel(), forwarders, device=dev, reduce_on_host=args.rehearse_on_one_gpu)
 
+    if args.batch > 1:
+        # B proposals per step: the four isolation fixtures of this N cycled (distinct matrices; the model
+        # layer that would produce them from theta stays on the CPU and is not part of the timed path)
+        ks = [k for k in ("iso%d_t%d" % (n_states, j) for j in range(4)) if k + "_pi" in d.files] or [key]
+        pis = np.stack([d[ks[b % len(ks)] + "_pi"] for b in range(args.batch)])
+        Ts = np.stack([d[ks[b % len(ks)] + "_T"] for b in range(args.batch)])
+        Es = np.stack([d[ks[b % len(ks)] + "_E"] for b in range(args.batch)])
+
     def step():
+        if args.batch > 1:
+            return float(ll.forward_params_batch(pis, Ts, Es)[0])
         return ll.forward_params(pi, T, E)
 
     def fence():
@@ -154,11 +166,11 @@ def main():
         total_cols = float(local_cols)
 
     if rank == 0:
-        cols_per_s = total_cols * args.steps / elapsed
+        cols_per_s = total_cols * args.batch * args.steps / elapsed
         k_ms = ms_p.value / max(n_p.value, 1)            # average propagate-kernel duration (HIP events)
         k_s = k_ms * 1e-3
-        alg_bytes = float(local_cols) * 1.0               # 1 B of observation stream per column
-        alg_flops = float(local_cols) * (2 * n_states * n_states + 3 * n_states)
+        alg_bytes = float(local_cols) * 1.0               # 1 B of observation stream per column (shared by a batch)
+        alg_flops = float(local_cols) * args.batch * (2 * n_states * n_states + 3 * n_states)
         exe_flops = (float(plan["vector_columns"]) * (2 * n_states * n_states + 3 * n_states)
                      + float(plan["vector_tokens"]) * (2 * n_states * n_states))
         kernel_name = plan["kernels"]
@@ -187,7 +199,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": workload, "states": n_states, "chunks_per_gpu": chunks_per_rank,
-                       "columns_per_chunk": cols, "evals_per_s": args.steps / elapsed,
+                       "columns_per_chunk": cols, "batch": args.batch, "evals_per_s": args.batch * args.steps / elapsed,
                        "segments": plan["segments"], "vectors": plan["vectors"],
                        "column_segment_len": plan["column_segment_len"], "token_segment_len": plan["token_segment_len"],
                        "compression": "pair dictionary, %d tokens" % plan["token_alphabet"] if plan["vector_tokens"] else "off",

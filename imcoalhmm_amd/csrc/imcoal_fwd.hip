@@ -356,10 +356,12 @@ size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 // Pick the segment length (in stream elements) that minimises a simple machine model: equal-length
 // wavefront tasks run in rounds of `resident` wavefronts at `step_cost` cycles per step; the serial
 // stitch adds ~stitch_cost per segment of the longest chunk.
-size_t choose_seglen(const std::vector<size_t> &lens, int N, int B, int VPW, double resident, double step_cost)
+size_t choose_seglen(const std::vector<size_t> &lens, int N, int B, int VPW, double resident, double step_cost,
+                     double *cost_out = nullptr)
 {
     size_t maxlen = 0;
     for (size_t L : lens) maxlen = std::max(maxlen, L);
+    if (cost_out) *cost_out = (double)maxlen * step_cost;
     if (maxlen <= 256) return std::max<size_t>(round_up(maxlen, 16), 16);
     const double stitch_cost = 12.0 * N + 300.0;   // cycles per stitched segment
     double best = 1e300;
@@ -379,6 +381,7 @@ size_t choose_seglen(const std::vector<size_t> &lens, int N, int B, int VPW, dou
         if (cost < best) { best = cost; best_seg = seg; }
         if (seg >= maxlen) break;
     }
+    if (cost_out) *cost_out = best;
     return best_seg;
 }
 
@@ -437,32 +440,56 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     for (Group &gr : p->groups) {
         std::vector<size_t> lens;
         for (int f : gr.chunks) lens.push_back(gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L);
-        if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);
-        else if (gr.big) {
+        if (gr.big) {
             // every non-first segment costs N^3 per step whatever the split: just fill the machine ~4x over
             size_t total = 0;
             for (size_t L : lens) total += L;
             const size_t target = std::max<size_t>(1, (size_t)4 * g.cus / (size_t)B);
             gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
-        } else if (kc->zip2 && g.kernel_pref != 1 && kc->zip2_lds(gr.A) <= LDS_BUDGET && (gr.zip || S == gr.A) &&
-                   [&] {   // operators must dominate first-segment vectors, or the blocked kernel idles 15/16 lanes
-                       size_t total = 0;
-                       for (size_t L : lens) total += L;
-                       const size_t target = std::max<size_t>(1, (size_t)g.cus * Z2WAVES * 4 / (size_t)B);
-                       gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
-                       size_t k = 0;
-                       for (size_t L : lens) k += (L + gr.seglen - 1) / gr.seglen;
-                       return g.kernel_pref == 2 || k >= 16 * lens.size();
-                   }()) {
-            gr.zip2 = true;   // gr.seglen set above
-        } else if (gr.zip) {
-            // LDS-bound: a workgroup of ZWAVES wavefronts serialises on one CU's LDS
-            const double lds_cycles = ((double)kc->R * kc->NP / 2 + kc->NP / 2.0) * 4.0 + kc->R * 6.0 + 40.0;
-            gr.seglen = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * ZWAVES, lds_cycles * ZWAVES / 4.0);
         } else {
-            gr.seglen = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * 4.0 * kc->minw,
-                                      4.0 * kc->R * kc->NP + 120.0);
+            // vector kernel (one vector per lane group) ...
+            double cost_vec = 0.0;
+            size_t seg_vec;
+            if (gr.zip) {
+                // LDS-bound: a workgroup of ZWAVES wavefronts serialises on one CU's LDS
+                const double lds_cycles = ((double)kc->R * kc->NP / 2 + kc->NP / 2.0) * 4.0 + kc->R * 6.0 + 40.0;
+                seg_vec = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * ZWAVES, lds_cycles * ZWAVES, &cost_vec);   // measured: 4600 cycles per wavefront-step at N=20
+            } else {
+                seg_vec = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * 4.0 * kc->minw,
+                                        4.0 * kc->R * kc->NP + 120.0, &cost_vec);
+            }
+            gr.seglen = seg_vec;
+            // ... or the register-blocked kernel (one operator per 16-lane row): fill every row of the machine
+            // once; first segments waste 1 - 1/N of their row, which the cost comparison accounts for
+            if (kc->zip2 && g.kernel_pref != 1 && kc->zip2_lds(gr.A) <= LDS_BUDGET && (gr.zip || S == gr.A)) {
+                size_t total = 0;
+                for (size_t L : lens) total += L;
+                const double rows = (double)g.cus * Z2WAVES * 4;
+                const double rb = kc->NP / 4.0;
+                const double step_cycles = 5.2 * rb * rb * kc->NP;          // per wavefront-step (4 rows), measured ~2600 at N=20
+                size_t seg_blk = 16;
+                double slots = 0.0, cost_blk = 1e300;
+                // a workgroup takes 32 consecutive segments of ONE chunk: rows are allocated per chunk in 32s
+                auto rows_used = [&](size_t sg) {
+                    double r = 0.0;
+                    for (size_t L : lens) r += std::ceil(std::ceil((double)L / (double)sg) / 32.0) * 32.0;
+                    return r;
+                };
+                for (int rounds = 1; rounds <= 16; ++rounds) {               // fill the machine's rows `rounds` times
+                    const double target = std::max(32.0, std::floor(rows * rounds / B));
+                    size_t sg = std::max<size_t>(16, round_up((size_t)std::ceil((double)total / target), 16));
+                    for (int it = 0; it < 256 && rows_used(sg) > target; ++it) sg += 16;
+                    const double used = rows_used(sg);
+                    const double c = std::ceil(used * B / rows) * (double)sg * 2.0 * step_cycles;
+                    if (c < cost_blk) { cost_blk = c; seg_blk = sg; slots = used; }
+                }
+                if (std::getenv("IMC_DEBUG"))
+                    std::fprintf(stderr, "[imc] plan: vector kernel seg %zu cost %.3g cycles; blocked kernel seg %zu slots %.0f cost %.3g cycles\n",
+                                 seg_vec, cost_vec, seg_blk, slots, cost_blk);
+                if (g.kernel_pref == 2 || cost_blk < cost_vec) { gr.zip2 = true; gr.seglen = seg_blk; }
+            }
         }
+        if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);   // tests: force stitching
     }
     // ---- segments in chunk order ----
     std::vector<SegDesc> segs;
