@@ -71,6 +71,9 @@ constexpr size_t DICT_TRAIN_MAX = 8u << 20;        // train on at most this pref
 struct DictDev {                                   // one trained dictionary + its device copy
     imc::PairDict dict;
     uint8_t *d_left = nullptr, *d_right = nullptr;
+    uint8_t *d_order = nullptr;                    // merged tokens sorted by (depth, id)
+    std::vector<uint8_t> order;                    // host copy of d_order
+    std::vector<int> depth;                        // per token; raw symbols have depth 0
 };
 
 struct Ev3 { hipEvent_t a, b, c; };   // a: before propagate, b: after propagate, c: after stitch
@@ -198,6 +201,15 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
             if (e2 == hipSuccess) e2 = hipMalloc((void **)&dd->d_right, imc::kMaxAlphabet);
             if (e2 == hipSuccess) e2 = hipMemcpy(dd->d_left, dd->dict.left, imc::kMaxAlphabet, hipMemcpyHostToDevice);
             if (e2 == hipSuccess) e2 = hipMemcpy(dd->d_right, dd->dict.right, imc::kMaxAlphabet, hipMemcpyHostToDevice);
+            dd->depth.assign(dd->dict.alphabet, 0);
+            for (int z = nsym; z < dd->dict.alphabet; ++z)
+                dd->depth[z] = 1 + std::max(dd->depth[dd->dict.left[z]], dd->depth[dd->dict.right[z]]);
+            for (int z = nsym; z < dd->dict.alphabet; ++z) dd->order.push_back((uint8_t)z);
+            std::stable_sort(dd->order.begin(), dd->order.end(),
+                             [&](uint8_t x, uint8_t y) { return dd->depth[x] < dd->depth[y]; });
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&dd->d_order, imc::kMaxAlphabet);
+            if (e2 == hipSuccess && !dd->order.empty())
+                e2 = hipMemcpy(dd->d_order, dd->order.data(), dd->order.size(), hipMemcpyHostToDevice);
             if (e2 != hipSuccess) {
                 obs_release(o);
                 delete o;
@@ -240,7 +252,8 @@ struct KernelChoice {
     size_t (*zip_lds)(int);
     ChainFn chain;
     bool zip_attr_set;
-    void (*big_table)(BigArgs);
+    void (*big_table_raw)(BigArgs);
+    void (*big_table_level)(BigArgs, const uint8_t *, int);
     void (*big_prop)(BigArgs);
     void (*zip2)(BigArgs);         // register-blocked token kernel (NP = 4 RB <= 24), else null
     size_t (*zip2_lds)(int);
@@ -252,7 +265,7 @@ KernelChoice make_kc()
 {
     constexpr int NP = R * G;
     KernelChoice k{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
-                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, nullptr, false};
+                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, nullptr, nullptr, false};
     if constexpr (NP % 4 == 0 && NP <= 24) {
         k.zip2 = k_zpropagate2<NP / 4>;
         k.zip2_lds = &Zip2Geom<NP / 4>::lds_bytes;
@@ -264,8 +277,8 @@ template <int NT>
 KernelChoice make_big()
 {
     constexpr int NP = 16 * NT;   // NT wavefronts per workgroup
-    return KernelChoice{0, NT, NP, 0, 1, nullptr, nullptr, nullptr, k_chain<NP, 0>, false, k_big_table<NT>,
-                        k_big_propagate<NT>, nullptr, nullptr, false};
+    return KernelChoice{0, NT, NP, 0, 1, nullptr, nullptr, nullptr, k_chain<NP, 0>, false, k_big_table_raw<NT>,
+                        k_big_table_level<NT>, k_big_propagate<NT>, nullptr, nullptr, false};
 }
 
 KernelChoice kChoices[] = {
@@ -441,10 +454,11 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         std::vector<size_t> lens;
         for (int f : gr.chunks) lens.push_back(gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L);
         if (gr.big) {
-            // every non-first segment costs N^3 per step whatever the split: just fill the machine ~4x over
+            // every segment costs N^3 per step whatever the split (one workgroup = one CU's worth of LDS), so
+            // one equal-length segment per CU is both balanced and the fewest operators for the stitch
             size_t total = 0;
             for (size_t L : lens) total += L;
-            const size_t target = std::max<size_t>(1, (size_t)4 * g.cus / (size_t)B);
+            const size_t target = std::max<size_t>(1, (size_t)g.cus / (size_t)B);
             gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
         } else {
             // vector kernel (one vector per lane group) ...
@@ -708,8 +722,30 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
             ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex; ba.scratch = gr.d_scratch;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
-            hipLaunchKernelGGL(kc->big_table, dim3((unsigned)B), dim3(kc->G * 64), 0, stream, ba);
+            hipLaunchKernelGGL(kc->big_table_raw, dim3((unsigned)S, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
+            if (gr.zip) {   // merged tokens, one launch per dictionary depth (tokens of a depth are independent)
+                const DictDev &dd = *gr.dict;
+                size_t i0 = 0;
+                while (i0 < dd.order.size()) {   // tokens >= A are not part of this level's alphabet: filtered below
+                    size_t i1 = i0;
+                    while (i1 < dd.order.size() && dd.depth[dd.order[i1]] == dd.depth[dd.order[i0]]) ++i1;
+                    // launch the contiguous sub-runs of [i0,i1) whose token id < A
+                    size_t r0 = i0;
+                    while (r0 < i1) {
+                        while (r0 < i1 && (int)dd.order[r0] >= gr.A) ++r0;
+                        size_t r1 = r0;
+                        while (r1 < i1 && (int)dd.order[r1] < gr.A) ++r1;
+                        if (r1 > r0) {
+                            hipLaunchKernelGGL(kc->big_table_level, dim3((unsigned)(r1 - r0), (unsigned)B), dim3(kc->G * 64), 0,
+                                               stream, ba, (const uint8_t *)dd.d_order, (int)r0);
+                            HIP_TRY(hipGetLastError());
+                        }
+                        r0 = r1;
+                    }
+                    i0 = i1;
+                }
+            }
             hipLaunchKernelGGL(kc->big_prop, dim3(ba.n_group_segs, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             note("k_big_propagate<" + std::to_string(kc->G) + ">" + strm);
             lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;

@@ -42,32 +42,77 @@ struct BigArgs {
 };
 
 
-// acc[tr][tc] += A(rows row0.., all k) * B(all k, cols col0..) for one workgroup-wide GEMM of size NP.
-// A and B are row-major NP x NP in global memory.  k is consumed in blocks of 16: lane l takes
-// k = kb*16 + 4*(l>>4) + s for s = 0..3 from both operands (any common order of k is a valid sum).
+// acc = A(rows row0.., all k) * B(all k, cols col0..) for one workgroup-wide GEMM of size NP; A and B are
+// row-major NP x NP in (L2-resident) global memory.  k is consumed in panels of 16: all NT wavefronts stage
+// the A panel (NP x 16) and the B panel (16 x NP) through LDS, double buffered - the global loads of panel
+// kb+1 are in flight while the MFMAs of panel kb run - so every operand byte is fetched once per
+// workgroup instead of once per wavefront, and one barrier per panel is the only synchronisation.
+// Lane l of a wavefront takes k = 4*(l>>4) + s (s = 0..3) of the panel from both operands.
+template <int NT>
+struct BigLds {
+    static constexpr int NP = 16 * NT;
+    static constexpr int APS = 18;        // A panel row stride (doubles): 16 + 2, keeps ds_read_b128 rows on distinct banks
+    static constexpr int BPS = NP + 4;    // B panel row stride (doubles): rows 4 apart land 32 banks apart
+    static constexpr int A_DOUBLES = NP * APS, B_DOUBLES = 16 * BPS;
+    static constexpr size_t bytes = (size_t)2 * (A_DOUBLES + B_DOUBLES) * 8;
+};
+
 template <int NT>
 __device__ __forceinline__ void big_gemm(const double *__restrict__ A, const double *__restrict__ B, int row0, int col0,
-                                         int lane, v4f64 (&acc)[2][NT / 2])
+                                         int tid, double *lds, v4f64 (&acc)[2][NT / 2])
 {
-    constexpr int NP = 16 * NT, TR = 2, TC = NT / 2;
-    const int lm = lane & 15, lg = lane >> 4;
+    using L = BigLds<NT>;
+    constexpr int NP = 16 * NT, TR = 2, TC = NT / 2, THREADS = NT * 64;
+    constexpr int APS = L::APS, BPS = L::BPS;
+    const int lane = tid & 63, lm = lane & 15, lg = lane >> 4;
+    // staging assignment: two double2 of the A panel (NP rows x 8 double2) and two of the B panel
+    // (16 rows x NP/2 double2) per thread; plain scalars so that nothing is demoted to scratch/LDS
+    const int e0 = tid, e1 = tid + THREADS;
+    const int ar0 = e0 >> 3, ac0 = e0 & 7, ar1 = e1 >> 3, ac1 = e1 & 7;
+    const int br0 = e0 / (NP / 2), bc0 = e0 - br0 * (NP / 2), br1 = e1 / (NP / 2), bc1 = e1 - br1 * (NP / 2);
+    const double *gA0 = A + (size_t)ar0 * NP + 2 * ac0, *gA1 = A + (size_t)ar1 * NP + 2 * ac1;
+    const double *gB0 = B + (size_t)br0 * NP + 2 * bc0, *gB1 = B + (size_t)br1 * NP + 2 * bc1;
+    const int lA0 = ar0 * APS + 2 * ac0, lA1 = ar1 * APS + 2 * ac1;
+    const int lB0 = L::A_DOUBLES + br0 * BPS + 2 * bc0, lB1 = L::A_DOUBLES + br1 * BPS + 2 * bc1;
+    double2 sa0, sa1, sb0, sb1;
+#define BIG_FETCH(kb_)                                                                 \
+    do {                                                                               \
+        sa0 = *reinterpret_cast<const double2 *>(gA0 + (kb_) * 16);                    \
+        sa1 = *reinterpret_cast<const double2 *>(gA1 + (kb_) * 16);                    \
+        sb0 = *reinterpret_cast<const double2 *>(gB0 + (size_t)(kb_) * 16 * NP);       \
+        sb1 = *reinterpret_cast<const double2 *>(gB1 + (size_t)(kb_) * 16 * NP);       \
+    } while (0)
+#define BIG_STAGE(buf_)                                                                \
+    do {                                                                               \
+        double *base_ = lds + (buf_) * (L::A_DOUBLES + L::B_DOUBLES);                  \
+        *reinterpret_cast<double2 *>(base_ + lA0) = sa0;                               \
+        *reinterpret_cast<double2 *>(base_ + lA1) = sa1;                               \
+        *reinterpret_cast<double2 *>(base_ + lB0) = sb0;                               \
+        *reinterpret_cast<double2 *>(base_ + lB1) = sb1;                               \
+    } while (0)
 #pragma unroll
     for (int tr = 0; tr < TR; ++tr)
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc) acc[tr][tc] = v4f64{0.0, 0.0, 0.0, 0.0};
+    BIG_FETCH(0);
+    BIG_STAGE(0);
+    __syncthreads();
 #pragma unroll 1
     for (int kb = 0; kb < NP / 16; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < NP / 16) BIG_FETCH(kb + 1);
+        const double *Al = lds + buf * (L::A_DOUBLES + L::B_DOUBLES), *Bl = Al + L::A_DOUBLES;
         double a[TR][4], bq[TC][4];
 #pragma unroll
         for (int tr = 0; tr < TR; ++tr) {
-            const double2 *ap = reinterpret_cast<const double2 *>(A + (size_t)(row0 + tr * 16 + lm) * NP + kb * 16 + 4 * lg);
+            const double2 *ap = reinterpret_cast<const double2 *>(Al + (row0 + tr * 16 + lm) * APS + 4 * lg);
             const double2 a01 = ap[0], a23 = ap[1];
             a[tr][0] = a01.x; a[tr][1] = a01.y; a[tr][2] = a23.x; a[tr][3] = a23.y;
         }
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) bq[tc][s] = B[(size_t)(kb * 16 + 4 * lg + s) * NP + col0 + tc * 16 + lm];
+            for (int s = 0; s < 4; ++s) bq[tc][s] = Bl[(4 * lg + s) * BPS + col0 + tc * 16 + lm];
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -75,7 +120,11 @@ __device__ __forceinline__ void big_gemm(const double *__restrict__ A, const dou
 #pragma unroll
                 for (int tc = 0; tc < TC; ++tc)
                     acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tr][s], bq[tc][s], acc[tr][tc], 0, 0, 0);
+        if (kb + 1 < NP / 16) BIG_STAGE(buf ^ 1);   // nobody reads buf^1 during this iteration
+        __syncthreads();
     }
+#undef BIG_FETCH
+#undef BIG_STAGE
 }
 
 // Workgroup-wide maximum of the (non-negative) accumulator entries -> exponent e with max in [2^(e-1), 2^e).
@@ -126,42 +175,46 @@ __device__ __forceinline__ void big_store(double *__restrict__ D, int row0, int 
             }
 }
 
-// Operator table for one parameter set: raw symbols C_s[i][j] = E[i][s] T[j][i], merged tokens
-// C_z = C_right * C_left (left is applied first), each normalised by a power of two.  One workgroup per
-// parameter set walks the dictionary in order (a token only depends on earlier ones).
+// Operator table.  k_big_table_raw: raw symbols C_s[i][j] = E[i][s] T[j][i] (one workgroup per symbol and
+// parameter set).  k_big_table_level: merged tokens C_z = C_right * C_left (left is applied first), each
+// normalised by a power of two; a token only depends on tokens of smaller depth, so the host launches one
+// grid per dictionary depth and all tokens of that depth are built concurrently.
 template <int NT>
-__global__ __launch_bounds__(NT * 64) void k_big_table(BigArgs a)
+__global__ __launch_bounds__(NT * 64) void k_big_table_raw(BigArgs a)
 {
     constexpr int NP = 16 * NT, BIG_THREADS = NT * 64;
-    __shared__ unsigned long long smax[2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    const int tid = threadIdx.x, s = blockIdx.x, b = blockIdx.y;
     const double *pp = a.params + (size_t)b * a.pstride;
     const double *Tp = pp + a.PP;
     const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
+    double *Cs = a.Ctab + ((size_t)b * a.A + s) * NP * NP;
+    for (int idx = tid; idx < NP * NP; idx += BIG_THREADS) {
+        const int i = idx / NP, j = idx - i * NP;
+        Cs[idx] = (i < a.N && j < a.N) ? Etg[(size_t)s * a.PP + i] * Tp[(size_t)j * a.PP + i] : 0.0;
+    }
+    if (tid == 0) a.cex[(size_t)b * a.A + s] = 0;
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT * 64) void k_big_table_level(BigArgs a, const uint8_t *order, int first)
+{
+    constexpr int NP = 16 * NT;
+    __shared__ unsigned long long smax[2];
+    __shared__ __attribute__((aligned(16))) double panels[BigLds<NT>::bytes / 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int z = order[first + blockIdx.x];
     double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
     int *cex = a.cex + (size_t)b * a.A;
-    for (int idx = tid; idx < a.S * NP * NP; idx += BIG_THREADS) {
-        const int s = idx / (NP * NP);
-        const int rem = idx - s * NP * NP;
-        const int i = rem / NP, j = rem - i * NP;
-        Ct[idx] = (i < a.N && j < a.N) ? Etg[(size_t)s * a.PP + i] * Tp[(size_t)j * a.PP + i] : 0.0;
-    }
-    if (tid < a.S) cex[tid] = 0;
     if (tid < 2) smax[tid] = 0ull;
-    __threadfence_block();
     __syncthreads();
     const int row0 = (wave >> 1) * 32, col0 = (wave & 1) * 8 * NT;
-    for (int z = a.S; z < a.A; ++z) {
-        const int zl = a.tok_left[z], zr = a.tok_right[z];
-        v4f64 acc[2][NT / 2];
-        big_gemm<NT>(Ct + (size_t)zr * NP * NP, Ct + (size_t)zl * NP * NP, row0, col0, lane, acc);
-        const int e = big_exponent<NT>(acc, smax, z & 1, tid);
-        big_store<NT>(Ct + (size_t)z * NP * NP, row0, col0, lane, acc, e, NP, NP, NP);
-        if (tid == 0) cex[z] = cex[zl] + cex[zr] + e;
-        __threadfence_block();
-        __syncthreads();
-    }
+    const int zl = a.tok_left[z], zr = a.tok_right[z];
+    v4f64 acc[2][NT / 2];
+    big_gemm<NT>(Ct + (size_t)zr * NP * NP, Ct + (size_t)zl * NP * NP, row0, col0, tid, panels, acc);
+    const int e = big_exponent<NT>(acc, smax, 0, tid);
+    big_store<NT>(Ct + (size_t)z * NP * NP, row0, col0, lane, acc, e, NP, NP, NP);
+    if (tid == 0) cex[z] = cex[zl] + cex[zr] + e;
 }
 
 // One workgroup per (segment, parameter set): P <- C_tok * P over the segment's tokens.
@@ -170,6 +223,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a)
 {
     constexpr int NP = 16 * NT, BIG_THREADS = NT * 64;
     __shared__ unsigned long long smax[2];
+    __shared__ __attribute__((aligned(16))) double panels[BigLds<NT>::bytes / 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const uint32_t seg = a.seg_ids[blockIdx.x];
@@ -204,7 +258,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a)
     int which = 0;
     for (int t = first ? 1 : 0; t < len; ++t) {
         const int tok = tokp[t];
-        big_gemm<NT>(Ct + (size_t)tok * NP * NP, cur, row0, col0, lane, acc);
+        big_gemm<NT>(Ct + (size_t)tok * NP * NP, cur, row0, col0, tid, panels, acc);
         const int e = big_exponent<NT>(acc, smax, which, tid);
         which ^= 1;
         big_store<NT>(nxt, row0, col0, lane, acc, e, NP, NP, NP);
