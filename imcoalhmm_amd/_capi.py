@@ -35,6 +35,10 @@ SIGNATURES = [
     ("imc_obs_create", ctypes.c_int, [_u8p, ctypes.c_size_t, ctypes.c_int, _vpp]),
     ("imc_obs_create_i32", ctypes.c_int, [_i32p, ctypes.c_size_t, ctypes.c_int, _vpp]),
     ("imc_obs_create_from_text", ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, _vpp]),
+    ("imc_read_observations", ctypes.c_int,
+     [ctypes.c_char_p, ctypes.c_int, _u8p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    ("imc_write_cache", ctypes.c_int, [ctypes.c_char_p, _u8p, ctypes.c_size_t, ctypes.c_int]),
+    ("imc_encode_pairwise", ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, _u8p]),
     ("imc_obs_length", ctypes.c_size_t, [ctypes.c_void_p]),
     ("imc_obs_nsym", ctypes.c_int, [ctypes.c_void_p]),
     ("imc_obs_compressed_length", ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),

@@ -43,6 +43,7 @@
 #include "kernels_big.hpp"
 #include "kernels_zip2.hpp"
 #include "pair_dict.hpp"
+#include "obs_io.hpp"
 
 namespace {
 
@@ -904,40 +905,39 @@ int imc_obs_create_from_text(const char *path, int nsym, imc_obs **out)
 {
     if (!out || !path) return fail(IMC_ERR_ARG, "null argument");
     if (nsym < 1 || nsym > 256) return fail(IMC_ERR_ARG, "nsym must be in [1,256]");
-    FILE *fp = std::fopen(path, "rb");
-    if (!fp) return fail(IMC_ERR_IO, std::string("cannot open ") + path + ": " + std::strerror(errno));
     std::vector<uint8_t> sym;
-    std::vector<char> buf(1 << 22);
-    long cur = -1;   // token being accumulated, -1 = none
-    size_t n;
-    int rc = IMC_OK;
-    while (rc == IMC_OK && (n = std::fread(buf.data(), 1, buf.size(), fp)) > 0) {
-        for (size_t i = 0; i < n; ++i) {
-            const unsigned char ch = (unsigned char)buf[i];
-            if (ch >= '0' && ch <= '9') {
-                cur = (cur < 0 ? 0 : cur) * 10 + (ch - '0');
-                if (cur > 1000000) cur = 1000000;
-            } else if (ch == ' ' || ch == '\n' || ch == '\t' || ch == '\r' || ch == '\f' || ch == '\v') {
-                if (cur >= 0) {
-                    if (cur >= nsym) { rc = fail(IMC_ERR_SYMBOL, "symbol " + std::to_string(cur) + " at column " + std::to_string(sym.size()) + " >= nsym"); break; }
-                    sym.push_back((uint8_t)cur);
-                    cur = -1;
-                }
-            } else {
-                rc = fail(IMC_ERR_IO, std::string("unexpected character in ") + path);   // int() would raise ValueError (hmm.py:14)
-                break;
-            }
-        }
-    }
-    std::fclose(fp);
-    if (rc != IMC_OK) return rc;
-    if (cur >= 0) {
-        if (cur >= nsym) return fail(IMC_ERR_SYMBOL, "symbol " + std::to_string(cur) + " >= nsym");
-        sym.push_back((uint8_t)cur);
-    }
+    const imc::IoResult r = imc::read_observation_file(path, nsym, sym);
+    if (r.code) return fail(r.code, r.msg);
     if (sym.size() >= (size_t)1 << 31) return fail(IMC_ERR_ARG, "chunk too long (limit 2^31-1 columns per chunk)");
     std::lock_guard<std::mutex> lk(g_mu);
     return obs_upload(sym.data(), sym.size(), nsym, out);
+}
+
+int imc_read_observations(const char *path, int nsym, uint8_t *sym_out, size_t capacity, size_t *length)
+{
+    if (!path || !length) return fail(IMC_ERR_ARG, "null argument");
+    if (nsym < 1 || nsym > 256) return fail(IMC_ERR_ARG, "nsym must be in [1,256]");
+    std::vector<uint8_t> sym;
+    const imc::IoResult r = imc::read_observation_file(path, nsym, sym);
+    if (r.code) return fail(r.code, r.msg);
+    *length = sym.size();
+    if (sym_out && capacity >= sym.size() && !sym.empty()) std::memcpy(sym_out, sym.data(), sym.size());
+    return IMC_OK;
+}
+
+int imc_write_cache(const char *path, const uint8_t *sym, size_t L, int nsym)
+{
+    if (!path || (L && !sym)) return fail(IMC_ERR_ARG, "null argument");
+    if (nsym < 1 || nsym > 256) return fail(IMC_ERR_ARG, "nsym must be in [1,256]");
+    const imc::IoResult r = imc::write_cache(path, sym, L, nsym);
+    return r.code ? fail(r.code, r.msg) : IMC_OK;
+}
+
+int imc_encode_pairwise(const char *seq1, const char *seq2, size_t L, uint8_t *sym_out)
+{
+    if (L && (!seq1 || !seq2 || !sym_out)) return fail(IMC_ERR_ARG, "null argument");
+    imc::encode_pairwise(seq1, seq2, L, sym_out);
+    return IMC_OK;
 }
 
 size_t imc_obs_length(const imc_obs *obs) { return obs ? obs->L : 0; }

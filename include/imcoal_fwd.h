@@ -59,7 +59,7 @@ int imc_obs_create(const uint8_t *sym, size_t L, int nsym, imc_obs **out);
 int imc_obs_create_i32(const int32_t *sym, size_t L, int nsym, imc_obs **out);   /* hmm.py:14 dtype */
 /* File of whitespace-separated decimal tokens, the format written by
  * scripts/prepare-alignments.py:92-105 and read at hmm.py:13-14. */
-int imc_obs_create_from_text(const char *path, int nsym, imc_obs **out);
+int imc_obs_create_from_text(const char *path, int nsym, imc_obs **out);   /* also accepts imc_write_cache files */
 size_t imc_obs_length(const imc_obs *obs);
 int imc_obs_nsym(const imc_obs *obs);
 /* Length of the chunk's pair-compressed token stream (the `new_obs` of hmm.py:16) at the deepest
@@ -67,6 +67,15 @@ int imc_obs_nsym(const imc_obs *obs);
  * (`new_nsyms`).  Returns the raw length when the chunk is not compressed. */
 size_t imc_obs_compressed_length(const imc_obs *obs, int alphabet_limit, int *alphabet_used);
 int imc_obs_free(imc_obs *obs);
+
+/* Host-side ingestion helpers (no GPU needed) -------------------------------------------- */
+/* Parse a text or cache file into caller memory.  Call with sym_out = NULL to get *length first. */
+int imc_read_observations(const char *path, int nsym, uint8_t *sym_out, size_t capacity, size_t *length);
+/* Packed on-disk cache of a chunk: 2 bits per column when nsym <= 4 (8x smaller than the text format). */
+int imc_write_cache(const char *path, const uint8_t *sym, size_t L, int nsym);
+/* The pairwise symbol rule of scripts/prepare-alignments.py:99-105 on two aligned sequences:
+ * 2 = either base not in ACGT (case-insensitive), 0 = equal, 1 = different. */
+int imc_encode_pairwise(const char *seq1, const char *seq2, size_t L, uint8_t *sym_out);
 
 /* Forward log-likelihood: replaces Forwarder.forward -> ziphmm.zip_forward,
  * src/IMCoalHMM/hmm.py:19-21, and the sum over forwarders at likelihood.py:33.

@@ -126,3 +126,51 @@ def test_synth_generator_is_deterministic(hmm_params):
     assert a.dtype == np.uint8 and a.size == 50_000 and (a == b).all()
     frac = np.bincount(a, minlength=3) / a.size
     assert frac[0] > 0.85 and 0.01 < frac[2] < 0.10
+
+
+def test_pairwise_encoder_matches_reference_rule(lib):
+    """scripts/prepare-alignments.py:99-105: 2 if either base not in ACGT, 0 if equal, 1 otherwise."""
+    from imcoalhmm_amd import prepare
+    rng = np.random.default_rng(0)
+    alphabet = np.array(list("ACGTacgtN-nRY"))
+    s1 = "".join(rng.choice(alphabet, size=5000))
+    s2 = "".join(rng.choice(alphabet, size=5000))
+    got = prepare.encode_pairwise(s1, s2)
+    clean = set("ACGT")
+    want = [2 if (a.upper() not in clean or b.upper() not in clean) else (0 if a.upper() == b.upper() else 1)
+            for a, b in zip(s1, s2)]
+    assert got.tolist() == want
+    with pytest.raises(ValueError):
+        prepare.encode_pairwise("ACG", "AC")
+
+
+def test_text_and_cache_files_round_trip(lib, tmp_path, example_pairs):
+    """Both on-disk formats parse back to the same symbols; the text one is the reference's own format."""
+    from imcoalhmm_amd import prepare
+    obs = example_pairs["hg18__pantro2"][:30001]
+    t, c = str(tmp_path / "pair.ziphmm"), str(tmp_path / "pair.imc")
+    prepare.write_text(t, obs)
+    prepare.write_cache(c, obs, 3)
+    assert open(t).read(12) == " ".join(str(int(s)) for s in obs[:6]) + " "
+    assert os.path.getsize(c) < os.path.getsize(t) / 7            # 2 bits vs 2 bytes per column
+    assert (prepare.read_observations(t, 3) == obs).all()
+    assert (prepare.read_observations(c, 3) == obs).all()
+    big = np.arange(200, dtype=np.uint8)                            # > 4 symbols: byte cache
+    prepare.write_cache(c, big, 200)
+    assert (prepare.read_observations(c, 256) == big).all()
+    with pytest.raises(ValueError):
+        prepare.read_observations(c, 100)                           # alphabet larger than requested nsym
+
+
+def test_prepare_cli_on_fasta_and_phylip(lib, tmp_path):
+    from imcoalhmm_amd import prepare
+    fa = tmp_path / "x.fa"
+    fa.write_text(">a desc\nACGTNAC\nGT\n>b\nACCTAAC\nGA\n>c\nAAAAAAAAA\n")
+    out = tmp_path / "ab.txt"
+    assert prepare.main([str(fa), str(out), "--names", "a,b"]) == 0
+    assert out.read_text() == "0 0 1 0 2 0 0 0 1 "
+    ph = tmp_path / "x.phy"
+    ph.write_text(" 2 9\na         ACGTNACGT\nb         ACCTAACGA\n")
+    out2 = tmp_path / "ab.imc"
+    assert prepare.main([str(ph), str(out2), "--in-format", "phylip", "--cache"]) == 0
+    assert prepare.read_observations(str(out2), 3).tolist() == [0, 0, 1, 0, 2, 0, 0, 0, 1]

@@ -169,6 +169,11 @@ def test_text_file_constructor(oracle, hmm_params, example_pairs, tmp_path):
     p2 = tmp_path / "nl.txt"
     p2.write_text("\n".join(str(int(s)) for s in obs[:100]))   # newline separated, no trailing space
     assert len(Forwarder(str(p2), 3)) == 100
+    from imcoalhmm_amd import prepare
+    p3 = tmp_path / "pair.imc"
+    prepare.write_cache(str(p3), obs, 3)                       # packed 2-bit cache, same constructor
+    g = Forwarder(str(p3), NSYM=3)
+    assert len(g) == obs.size and g.forward(pi, T, E) == f.forward(pi, T, E)
 
 
 @pytest.mark.parametrize("n", [1, 3, 4, 8, 10, 12, 16, 20, 23, 24, 28, 32, 37, 40, 70, 150])
