@@ -425,13 +425,45 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     else
         for (int A = 1; A <= imc::kMaxAlphabet; ++A)
             if (kc->zip_lds(A) <= LDS_BUDGET) a_max = A;
+    // One dictionary level per dictionary: the deepest level is not always the best - every workgroup rebuilds
+    // the operator table per evaluation ((A - S) dependent small products), which dominates on short inputs.
+    // Estimate: table build + main loop with all 16-lane rows of the machine busy.
+    std::map<const DictDev *, int> dict_level;
+    if (g.compression) {
+        std::map<const DictDev *, std::vector<int>> by_dict;
+        for (int f = 0; f < n_chunks; ++f)
+            if (chunks[f]->dict && chunks[f]->nsym == S) by_dict[chunks[f]->dict.get()].push_back(f);
+        for (auto &kv : by_dict) {
+            double best = 1e300;
+            int best_l = -1;
+            for (int l = 0; l < imc::kNumLevels; ++l) {
+                const imc_obs *o0 = chunks[kv.second[0]];
+                if (!(o0->alphabet[l] <= a_max && o0->alphabet[l] > o0->nsym && o0->d_tok[l])) continue;
+                double toks = 0.0;
+                for (int f : kv.second) toks += (double)chunks[f]->ntok[l];
+                const double n3 = (double)kc->NP * kc->NP * kc->NP;
+                double c_tab, c_main;   // cycles
+                if (big) {   // one GEMM per step per workgroup (~0.027 n^3 cycles measured at N=150), table built by depth
+                    const double gemm = 0.027 * n3 + 20000.0;
+                    c_tab = ((o0->alphabet[l] - S) / 6.0 + 2.0) * gemm;
+                    c_main = std::max(16.0, toks * B / (double)g.cus) * gemm;
+                } else {     // ~5200 cycles per row-step at N=20; every workgroup rebuilds the table
+                    c_tab = (o0->alphabet[l] - S) * (400.0 + n3 / 64.0);
+                    c_main = std::max(16.0, toks * B / ((double)g.cus * 32.0)) * 0.65 * n3;
+                }
+                if (c_tab + c_main < best) { best = c_tab + c_main; best_l = l; }
+            }
+            dict_level[kv.first] = best_l;
+        }
+    }
     std::vector<int> chunk_group(n_chunks, -1);
     for (int f = 0; f < n_chunks; ++f) {
         const imc_obs *o = chunks[f];
         int level = -1;
-        if (g.compression && o->dict && o->nsym == S)
-            for (int l = 0; l < imc::kNumLevels; ++l)
-                if (o->alphabet[l] <= a_max && o->alphabet[l] > o->nsym && o->d_tok[l]) level = l;
+        if (g.compression && o->dict && o->nsym == S) {
+            auto it = dict_level.find(o->dict.get());
+            if (it != dict_level.end()) level = it->second;
+        }
         int gi = -1;
         for (size_t q = 0; q < p->groups.size(); ++q) {
             Group &gr = p->groups[q];
