@@ -90,6 +90,8 @@ struct Ctx {
     int compression = 1;      // 0 = raw symbol stream, 1 = pair-compressed token stream where possible
     int kernel_pref = 0;      // 0 = automatic, 1 = vector kernels (k_propagate / k_zpropagate), 2 = blocked (k_zpropagate2)
     bool profile = false;
+    bool use_graphs = false;  // IMC_GRAPH=1: replay each plan's launch sequence as a hipGraph (measured: no gain, the
+                              // per-evaluation latency is kernel time + kernel boundaries, not host launch cost)
     std::vector<Ev3> events;
     std::map<int, std::shared_ptr<DictDev>> dicts;   // by raw alphabet size
     uint64_t last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -125,6 +127,7 @@ int ensure_ctx()
         return fail(IMC_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     g.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    g.use_graphs = std::getenv("IMC_GRAPH") != nullptr;
     g.pid = me;
     g.ready = true;
     return IMC_OK;
@@ -346,8 +349,14 @@ struct Plan {
     uint64_t chain_steps = 0;        // serial depth of the stitch (sum over levels of the longest chain)
     double *d_params = nullptr, *d_out = nullptr;
     double *h_params = nullptr, *h_out = nullptr;   // pinned
+    double *h_out_dev = nullptr;                    // device-visible alias of h_out (k_finish writes results straight to the host)
+    hipGraphExec_t graph = nullptr;                 // captured enqueue(), replayed by run_batch
+    uint64_t calls = 0;
+    uint64_t lp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::string kernels;
     void release()
     {
+        if (graph) (void)hipGraphExecDestroy(graph);
         (void)hipFree(d_segs); (void)hipFree(d_vecs); (void)hipFree(d_final_vec);
         for (auto &l : levels) l.release();
         for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_seg_out); (void)hipFree(gr.d_blocks); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_scratch); (void)hipFree(gr.d_cex); }
@@ -682,7 +691,8 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_params, (size_t)B * q->pstride * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_out, (size_t)B * std::max(n_chunks, 1) * 8);
     if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_params, (size_t)B * q->pstride * 8, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_out, (size_t)B * std::max(n_chunks, 1) * 8, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_out, (size_t)B * std::max(n_chunks, 1) * 8, hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&q->h_out_dev, q->h_out, 0);
     if (e != hipSuccess) {
         q->release();
         return fail(e == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
@@ -711,11 +721,11 @@ int check_args(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, 
 }
 
 // Enqueue everything for one batch on `stream`.  Results land in plan->d_out ([B][n_chunks]).
-int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipStream_t stream)
+// Pad the caller's parameters into the plan's pinned staging buffer (host work only).
+void stage_params(Plan *p, const double *pis, const double *Ts, const double *Es)
 {
     KernelChoice *kc = p->kc;
     const int N = p->N, S = p->S, NP = kc->NP, B = p->B;
-    // pad parameters into the pinned staging buffer
     for (int b = 0; b < B; ++b) {
         double *pp = p->h_params + (size_t)b * p->pstride;
         std::memset(pp, 0, p->pstride * 8);
@@ -727,9 +737,18 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
         for (int s = 0; s < S; ++s)
             for (int i = 0; i < N; ++i) Et[(size_t)s * NP + i] = E[(size_t)i * S + s];
     }
+}
+
+// Enqueue one batch evaluation on `stream`: parameter upload, propagate, stitch.  Per-chunk results are written
+// to `out` ([B][n_chunks]; device memory or mapped pinned host memory).  Contains no synchronisation, so the
+// same call sequence can be captured into a hipGraph.
+int enqueue(Plan *p, hipStream_t stream, double *out)
+{
+    KernelChoice *kc = p->kc;
+    const int N = p->N, S = p->S, NP = kc->NP, B = p->B;
     HIP_TRY(hipMemcpyAsync(p->d_params, p->h_params, (size_t)B * p->pstride * 8, hipMemcpyHostToDevice, stream));
 
-    uint64_t *lp = g.last_plan;
+    uint64_t *lp = p->lp;
     lp[0] = p->n_segs; lp[1] = p->n_vecs; lp[2] = lp[3] = lp[4] = lp[5] = lp[6] = lp[7] = 0;
     Ev3 ev{nullptr, nullptr, nullptr};
     const bool prof = g.profile && p->n_vecs;
@@ -737,8 +756,8 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
         HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); HIP_TRY(hipEventCreate(&ev.c));
         HIP_TRY(hipEventRecord(ev.a, stream));
     }
-    g.last_kernels.clear();
-    auto note = [&](const std::string &k) { g.last_kernels += (g.last_kernels.empty() ? "" : "+") + k; };
+    p->kernels.clear();
+    auto note = [&](const std::string &k) { p->kernels += (p->kernels.empty() ? "" : "+") + k; };
     for (const Group &gr : p->groups) {
         if (!gr.n_vecs) continue;
         const std::string strm = gr.zip ? "[tokens]" : "[columns]";
@@ -838,7 +857,7 @@ int enqueue(Plan *p, const double *pis, const double *Ts, const double *Es, hipS
     if (p->n_chunks) {
         const Level &last = p->levels.back();
         hipLaunchKernelGGL(k_finish, dim3((p->n_chunks + 63) / 64, (unsigned)B), dim3(64), 0, stream,
-                           p->d_final_vec, p->n_chunks, N, NP, last.n_vecs, last.d_P, last.d_EX, p->d_out);
+                           p->d_final_vec, p->n_chunks, N, NP, last.n_vecs, last.d_P, last.d_EX, out);
         HIP_TRY(hipGetLastError());
     }
     if (prof) {
@@ -857,9 +876,26 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
     HIP_TRY(hipSetDevice(g.device));
     Plan *p = nullptr;
     if (int rc = build_plan(chunks, n_chunks, N, S, B, &p)) return rc;
-    if (int rc = enqueue(p, pis, Ts, Es, g.stream)) return rc;
-    if (n_chunks)
-        HIP_TRY(hipMemcpyAsync(p->h_out, p->d_out, (size_t)B * n_chunks * 8, hipMemcpyDeviceToHost, g.stream));
+    stage_params(p, pis, Ts, Es);
+    // First call of a plan runs eagerly (kernel attributes get set); the second is captured into a hipGraph that
+    // every later call replays: one graph launch instead of ~8 stream operations per evaluation.
+    const bool use_graph = !g.profile && g.use_graphs && p->calls >= 1;
+    if (use_graph && !p->graph) {
+        hipGraph_t gr = nullptr;
+        HIP_TRY(hipStreamBeginCapture(g.stream, hipStreamCaptureModeThreadLocal));
+        const int rc = enqueue(p, g.stream, p->h_out_dev);
+        const hipError_t ec = hipStreamEndCapture(g.stream, &gr);
+        if (rc) { if (gr) (void)hipGraphDestroy(gr); return rc; }
+        if (ec != hipSuccess) return fail(IMC_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
+        const hipError_t ei = hipGraphInstantiate(&p->graph, gr, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(gr);
+        if (ei != hipSuccess) { p->graph = nullptr; return fail(IMC_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+    }
+    if (use_graph) HIP_TRY(hipGraphLaunch(p->graph, g.stream));
+    else if (int rc = enqueue(p, g.stream, p->h_out_dev)) return rc;
+    ++p->calls;
+    for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
+    g.last_kernels = p->kernels;
     HIP_TRY(hipStreamSynchronize(g.stream));
     for (int b = 0; b < B; ++b) {
         double tot = 0.0;   // Python sum(): left to right from 0 (likelihood.py:33)
@@ -1040,7 +1076,11 @@ int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, 
     if (int rc = build_plan(chunks, n_chunks, N, S, B, &p)) return rc;
     // the pinned staging buffer is reused by the next call: wait for the previous upload first
     HIP_TRY(hipStreamSynchronize(st));
-    if (int rc = enqueue(p, pis, Ts, Es, st)) return rc;
+    stage_params(p, pis, Ts, Es);
+    if (int rc = enqueue(p, st, p->d_out)) return rc;
+    ++p->calls;
+    for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
+    g.last_kernels = p->kernels;
     hipLaunchKernelGGL(k_sum_chunks, dim3((B + 63) / 64), dim3(64), 0, st, p->d_out, n_chunks, B, d_out_partial);
     HIP_TRY(hipGetLastError());
     return IMC_OK;
