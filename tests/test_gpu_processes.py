@@ -1,0 +1,55 @@
+"""The reference's MC3 builds its Forwarders inside multiprocessing children (mcmc.py:99-145: one OS process per
+chain, `_set_chain()` constructs Forwarders + Likelihood in the child, results come back through Queues).  The
+library touches HIP lazily and per PID, so that pattern must work: a parent that never used the GPU forks two
+chain processes, each builds its own Forwarder and evaluates."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = textwrap.dedent('''
+    import multiprocessing as mp, os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+
+    def chain(k, q, path):
+        from imcoalhmm_amd import Forwarder, Likelihood            # first HIP use happens here, in the child
+        d = np.load(os.path.join(%r, "tests", "golden", "hmm_params.npz"))
+        pi, T, E = d["iso10_t%%d_pi" %% k], d["iso10_t%%d_T" %% k], d["iso10_t%%d_E" %% k]
+        class M(object):
+            def valid_parameters(self, p): return True
+            def build_hidden_markov_model(self, p): return pi, T, E
+        ll = Likelihood(M(), [Forwarder(path, NSYM=3)])
+        q.put((k, ll(np.array([1.0]))))
+
+    if __name__ == "__main__":
+        ctx = mp.get_context("fork")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=chain, args=(k, q, sys.argv[1])) for k in range(2)]
+        for p in ps: p.start()
+        res = dict(q.get(timeout=120) for _ in ps)
+        for p in ps:
+            p.join(60)
+            assert p.exitcode == 0
+        print(repr(res[0]), repr(res[1]))
+''') % (REPO, REPO)
+
+
+def test_forwarders_built_in_forked_children(tmp_path, oracle, hmm_params, example_pairs):
+    obs = example_pairs["hg18__pantro2"]
+    path = tmp_path / "pair.txt"
+    path.write_text(" ".join(str(int(s)) for s in obs) + " ")
+    script = tmp_path / "chains.py"
+    script.write_text(SCRIPT)
+    out = subprocess.run([sys.executable, str(script), str(path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    a, b = (float(x) for x in out.stdout.split()[-2:])
+    for got, key in ((a, "iso10_t0"), (b, "iso10_t1")):
+        want = oracle.forward_scaled(*hmm_params(key), obs)
+        assert abs(got - want) / abs(want) < 1e-11
