@@ -511,8 +511,9 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
                 const double lds_cycles = ((double)kc->R * kc->NP / 2 + kc->NP / 2.0) * 4.0 + kc->R * 6.0 + 40.0;
                 seg_vec = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * ZWAVES, lds_cycles * ZWAVES, &cost_vec);   // measured: 4600 cycles per wavefront-step at N=20
             } else {
+                // VALU-bound, minw wavefronts share a SIMD: measured 555 cycles per wavefront-column per SIMD at N=20
                 seg_vec = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * 4.0 * kc->minw,
-                                        4.0 * kc->R * kc->NP + 120.0, &cost_vec);
+                                        kc->minw * 1.7 * (4.0 * kc->R * kc->NP + 16.0), &cost_vec);
             }
             gr.seglen = seg_vec;
             // ... or the register-blocked kernel (one operator per 16-lane row): fill every row of the machine
@@ -522,7 +523,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
                 for (size_t L : lens) total += L;
                 const double rows = (double)g.cus * Z2WAVES * 4;
                 const double rb = kc->NP / 4.0;
-                const double step_cycles = 5.2 * rb * rb * kc->NP;          // per wavefront-step (4 rows), measured ~2600 at N=20
+                const double step_cycles = 5.8 * rb * rb * kc->NP;          // per wavefront-step (4 rows), measured ~2900 at N=20
                 size_t seg_blk = 16;
                 double slots = 0.0, cost_blk = 1e300;
                 // a workgroup takes 32 consecutive segments of ONE chunk: rows are allocated per chunk in 32s
