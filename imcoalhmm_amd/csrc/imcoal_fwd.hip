@@ -258,7 +258,9 @@ struct KernelChoice {
     bool zip_attr_set;
     void (*big_table_raw)(BigArgs);
     void (*big_table_level)(BigArgs, const uint8_t *, int);
-    void (*big_prop)(BigArgs);
+    void (*big_prop)(BigArgs, const BigBlock *);
+    int big_nslab;
+    size_t big_lds;
     void (*zip2)(BigArgs);         // register-blocked token kernel (NP = 4 RB <= 24), else null
     size_t (*zip2_lds)(int);
     bool zip2_attr_set;
@@ -269,7 +271,7 @@ KernelChoice make_kc()
 {
     constexpr int NP = R * G;
     KernelChoice k{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
-                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, nullptr, nullptr, false};
+                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, false};
     if constexpr (NP % 4 == 0 && NP <= 24) {
         k.zip2 = k_zpropagate2<NP / 4>;
         k.zip2_lds = &Zip2Geom<NP / 4>::lds_bytes;
@@ -277,19 +279,20 @@ KernelChoice make_kc()
     return k;
 }
 
-template <int NT>
+template <int NT, int NSLAB>
 KernelChoice make_big()
 {
     constexpr int NP = 16 * NT;   // NT wavefronts per workgroup
     return KernelChoice{0, NT, NP, 0, 1, nullptr, nullptr, nullptr, k_chain<NP, 0>, false, k_big_table_raw<NT>,
-                        k_big_table_level<NT>, k_big_propagate<NT>, nullptr, nullptr, false};
+                        k_big_table_level<NT>, k_big_propagate<NT, NSLAB>, NSLAB, BigSlab<NT, NSLAB>::bytes,
+                        nullptr, nullptr, false};
 }
 
 KernelChoice kChoices[] = {
     make_kc<4, 1, 2>(), make_kc<4, 2, 2>(), make_kc<4, 3, 2>(), make_kc<4, 4, 2>(), make_kc<4, 5, 2>(),
     make_kc<3, 8, 2>(), make_kc<2, 14, 2>(), make_kc<2, 16, 2>(), make_kc<2, 20, 1>(), make_kc<1, 48, 1>(),
     make_kc<1, 56, 1>(), make_kc<1, 64, 1>(),
-    make_big<6>(), make_big<8>(), make_big<10>(), make_big<12>(),
+    make_big<6, 1>(), make_big<8, 2>(), make_big<10, 2>(), make_big<12, 3>(),
 };
 constexpr int IMC_MAX_N = 192;
 
@@ -307,6 +310,8 @@ struct Group {             // one propagate launch
     bool zip2 = false;     // register-blocked token kernel (one 16-lane row per segment)
     std::vector<uint32_t> seg_ids, seg_out;   // big: segment ids and their level-0 vector index
     std::vector<Z2Block> blocks;              // zip2: one entry per workgroup
+    std::vector<BigBlock> big_blocks;         // big: one entry per (segment, column slab) workgroup
+    BigBlock *d_big_blocks = nullptr;
     uint32_t *d_seg_ids = nullptr, *d_seg_out = nullptr;
     Z2Block *d_blocks = nullptr;
     double *d_Ctab = nullptr, *d_scratch = nullptr;
@@ -359,7 +364,7 @@ struct Plan {
         if (graph) (void)hipGraphExecDestroy(graph);
         (void)hipFree(d_segs); (void)hipFree(d_vecs); (void)hipFree(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_seg_out); (void)hipFree(gr.d_blocks); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_scratch); (void)hipFree(gr.d_cex); }
+        for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_seg_out); (void)hipFree(gr.d_blocks); (void)hipFree(gr.d_big_blocks); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_scratch); (void)hipFree(gr.d_cex); }
         (void)hipFree(d_params); (void)hipFree(d_out);
         (void)hipHostFree(h_params); (void)hipHostFree(h_out);
     }
@@ -683,11 +688,29 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         if (gr.zip2 && e == hipSuccess) e = up((void **)&gr.d_blocks, gr.blocks.data(), gr.blocks.size() * sizeof(Z2Block));
         if (!gr.big || e != hipSuccess) continue;
         const size_t np2 = (size_t)kc->NP * kc->NP;
-        e = up((void **)&gr.d_seg_ids, gr.seg_ids.data(), gr.seg_ids.size() * 4);
-        if (e == hipSuccess) e = up((void **)&gr.d_seg_out, gr.seg_out.data(), gr.seg_out.size() * 4);
+        // workgroup list: slabs of one segment 8 ids apart (same XCD -> they share the operator rows in L2)
+        {
+            std::vector<BigBlock> lin;
+            for (size_t i2 = 0; i2 < gr.seg_ids.size(); ++i2) {
+                const bool fst = seg_first[gr.seg_ids[i2]] != 0;
+                for (int sl = 0; sl < (fst ? 1 : kc->big_nslab); ++sl)
+                    lin.push_back(BigBlock{gr.seg_ids[i2], (uint32_t)sl, gr.seg_out[i2], 0u});
+            }
+            // lin is segment-major; re-deal non-first segments in tiles of 8 segments x nslab
+            gr.big_blocks.clear();
+            std::vector<BigBlock> firsts, rest;
+            for (const BigBlock &bb : lin) (seg_first[bb.seg] ? firsts : rest).push_back(bb);
+            const size_t ns = (size_t)kc->big_nslab;
+            for (size_t base = 0; base < rest.size(); base += 8 * ns) {
+                const size_t nseg = std::min<size_t>(8, (rest.size() - base) / ns);
+                for (size_t sl = 0; sl < ns; ++sl)
+                    for (size_t k2 = 0; k2 < nseg; ++k2) gr.big_blocks.push_back(rest[base + k2 * ns + sl]);
+            }
+            for (const BigBlock &bb : firsts) gr.big_blocks.push_back(bb);
+        }
+        e = up((void **)&gr.d_big_blocks, gr.big_blocks.data(), gr.big_blocks.size() * sizeof(BigBlock));
         if (e == hipSuccess) e = hipMalloc((void **)&gr.d_Ctab, (size_t)B * gr.A * np2 * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&gr.d_cex, (size_t)B * gr.A * 4 + 16);
-        if (e == hipSuccess) e = hipMalloc((void **)&gr.d_scratch, (size_t)B * std::max<size_t>(gr.seg_ids.size(), 1) * 2 * np2 * 8);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_params, (size_t)B * q->pstride * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_out, (size_t)B * std::max(n_chunks, 1) * 8);
@@ -773,7 +796,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.n_group_segs = (uint32_t)gr.seg_ids.size(); ba.n_vecs_total = p->n_vecs;
             ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
-            ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex; ba.scratch = gr.d_scratch;
+            ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex; ba.scratch = nullptr;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
             hipLaunchKernelGGL(kc->big_table_raw, dim3((unsigned)S, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
@@ -799,7 +822,13 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                     i0 = i1;
                 }
             }
-            hipLaunchKernelGGL(kc->big_prop, dim3(ba.n_group_segs, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
+            if (!kc->zip_attr_set) {   // (flag reused: dynamic LDS size of the large-N propagate kernel)
+                HIP_TRY(hipFuncSetAttribute((const void *)kc->big_prop, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)LDS_BUDGET));
+                kc->zip_attr_set = true;
+            }
+            hipLaunchKernelGGL(kc->big_prop, dim3((unsigned)gr.big_blocks.size(), (unsigned)B), dim3(kc->G * 64), kc->big_lds,
+                               stream, ba, (const BigBlock *)gr.d_big_blocks);
             note("k_big_propagate<" + std::to_string(kc->G) + ">" + strm);
             lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
         } else if (gr.zip2) {

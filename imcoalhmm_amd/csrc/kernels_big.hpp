@@ -36,7 +36,7 @@ struct BigArgs {
     const uint8_t *tok_left, *tok_right;
     double *Ctab;                 // [B][A][NP][NP] operator table (row-major, zero padded)
     int *cex;                     // [B][A] power-of-two exponents of the table entries
-    double *scratch;              // [B][n_group_segs][2][NP][NP]
+    double *scratch;              // unused (P lives in LDS slabs)
     double *P;                    // level-0 results (see kernels_stitch.hpp for the layout)
     int *EX;
 };
@@ -217,68 +217,151 @@ __global__ __launch_bounds__(NT * 64) void k_big_table_level(BigArgs a, const ui
     if (tid == 0) cex[z] = cex[zl] + cex[zr] + e;
 }
 
-// One workgroup per (segment, parameter set): P <- C_tok * P over the segment's tokens.
-template <int NT>
-__global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a)
+// One workgroup per (segment, column slab, parameter set): P[:, slab] <- C_tok * P[:, slab] over the segment's
+// tokens.  Columns of P are independent, so a segment is split into NSLAB column slabs of SC = NP/NSLAB
+// columns that live in LDS for the whole launch (the B operand is read straight from the slab, the result
+// is written back into it after each step): P never touches global memory, and the only streamed operand
+// is the token operator's 16-deep A panels (double-buffered through LDS).  Wavefront w owns tile-row w:
+// NT/NSLAB accumulator tiles.  Slabs of one segment are given block ids 8 apart so that they land on the
+// same XCD and share the operator rows in its L2.
+struct BigBlock {
+    uint32_t seg;        // segment id
+    uint32_t slab;       // column slab index
+    uint32_t out_vec0;   // level-0 vector index of the segment's result
+    uint32_t pad;
+};
+
+template <int NT, int NSLAB>
+struct BigSlab {
+    static constexpr int NP = 16 * NT;
+    static constexpr int SC = NP / NSLAB;       // columns per slab
+    static constexpr int TCS = NT / NSLAB;      // tile-columns per slab
+    static constexpr int SPS = SC + 4;          // slab row stride (doubles): k rows 4 apart land 32 banks apart
+    static constexpr int APS = 18;              // A panel row stride
+    static constexpr int SLAB_DOUBLES = NP * SPS, A_DOUBLES = NP * APS;
+    static constexpr size_t bytes = (size_t)(SLAB_DOUBLES + 2 * A_DOUBLES) * 8;
+    static_assert(NT % NSLAB == 0, "tile columns must divide evenly over the slabs");
+};
+
+template <int NT, int NSLAB>
+__global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigBlock *blocks)
 {
-    constexpr int NP = 16 * NT, BIG_THREADS = NT * 64;
+    using G = BigSlab<NT, NSLAB>;
+    constexpr int NP = G::NP, SC = G::SC, TCS = G::TCS, SPS = G::SPS, APS = G::APS, THREADS = NT * 64;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *slab = lds;                              // [NP][SPS]  P[k][c - c0]
+    double *Apan = lds + G::SLAB_DOUBLES;            // [2][NP][APS]
     __shared__ unsigned long long smax[2];
-    __shared__ __attribute__((aligned(16))) double panels[BigLds<NT>::bytes / 8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
     const int b = blockIdx.y;
-    const uint32_t seg = a.seg_ids[blockIdx.x];
-    const SegDesc sd = a.segs[seg];
+    const BigBlock bk = blocks[blockIdx.x];
+    const SegDesc sd = a.segs[bk.seg];
     const bool first = sd.first != 0;
     const int len = (int)sd.len;
     const uint8_t *tokp = sd.obs;
+    const int c0 = (int)bk.slab * SC;                // first global column of this slab
     const double *pp = a.params + (size_t)b * a.pstride;
     const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
     const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
     const int *cex = a.cex + (size_t)b * a.A;
-    double *buf0 = a.scratch + ((size_t)b * a.n_group_segs + blockIdx.x) * 2 * NP * NP;
-    double *buf1 = buf0 + (size_t)NP * NP;
 
-    // initial P: identity, or (first segment) column 0 = pi .* E[:,o_0] and nothing else
+    // initial slab: identity columns, or (first segment, slab 0) column 0 = pi .* E[:,o_0]
     const int tok0 = first ? (int)tokp[0] : 0;
-    for (int idx = tid; idx < NP * NP; idx += BIG_THREADS) {
-        const int i = idx / NP, j = idx - i * NP;
+    for (int idx = tid; idx < NP * SC; idx += THREADS) {
+        const int k = idx / SC, c = idx - k * SC;
         double v;
-        if (first) v = (j == 0 && i < a.N) ? pp[i] * Etg[(size_t)tok0 * a.PP + i] : 0.0;
-        else v = (i == j && i < a.N) ? 1.0 : 0.0;
-        buf0[idx] = v;
+        if (first) v = (c0 + c == 0 && k < a.N) ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
+        else v = (k == c0 + c && k < a.N) ? 1.0 : 0.0;
+        slab[k * SPS + c] = v;
     }
     if (tid < 2) smax[tid] = 0ull;
-    __threadfence_block();
     __syncthreads();
 
-    const int row0 = (wave >> 1) * 32, col0 = (wave & 1) * 8 * NT;
+    // A-panel staging: NP rows x 8 double2 per panel, two per thread
+    const int e0 = tid, e1 = tid + THREADS;
+    const int ar0 = e0 >> 3, ac0 = e0 & 7, ar1 = e1 >> 3, ac1 = e1 & 7;
+    const int lA0 = ar0 * APS + 2 * ac0, lA1 = ar1 * APS + 2 * ac1;
+    const int row0 = wave * 16;
     long long ex = 0;
-    double *cur = buf0, *nxt = buf1;
-    v4f64 acc[2][NT / 2];
     int which = 0;
     for (int t = first ? 1 : 0; t < len; ++t) {
         const int tok = tokp[t];
-        big_gemm<NT>(Ct + (size_t)tok * NP * NP, cur, row0, col0, tid, panels, acc);
-        const int e = big_exponent<NT>(acc, smax, which, tid);
-        which ^= 1;
-        big_store<NT>(nxt, row0, col0, lane, acc, e, NP, NP, NP);
-        ex += cex[tok] + e;
-        __threadfence_block();
+        const double *A = Ct + (size_t)tok * NP * NP;
+        const double *gA0 = A + (size_t)ar0 * NP + 2 * ac0, *gA1 = A + (size_t)ar1 * NP + 2 * ac1;
+        v4f64 acc[TCS];
+#pragma unroll
+        for (int tc = 0; tc < TCS; ++tc) acc[tc] = v4f64{0.0, 0.0, 0.0, 0.0};
+        double2 sa0 = *reinterpret_cast<const double2 *>(gA0), sa1 = *reinterpret_cast<const double2 *>(gA1);
+        *reinterpret_cast<double2 *>(Apan + lA0) = sa0;
+        *reinterpret_cast<double2 *>(Apan + lA1) = sa1;
         __syncthreads();
-        double *tmp = cur; cur = nxt; nxt = tmp;
+#pragma unroll 1
+        for (int kb = 0; kb < NP / 16; ++kb) {
+            const int buf = kb & 1;
+            if (kb + 1 < NP / 16) {
+                sa0 = *reinterpret_cast<const double2 *>(gA0 + (kb + 1) * 16);
+                sa1 = *reinterpret_cast<const double2 *>(gA1 + (kb + 1) * 16);
+            }
+            const double *Al = Apan + buf * G::A_DOUBLES;
+            const double2 *ap = reinterpret_cast<const double2 *>(Al + (row0 + lm) * APS + 4 * lg);
+            const double2 a01 = ap[0], a23 = ap[1];
+            const double av[4] = {a01.x, a01.y, a23.x, a23.y};
+            const double *Bk = slab + (size_t)(kb * 16 + 4 * lg) * SPS + lm;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                for (int tc = 0; tc < TCS; ++tc)
+                    acc[tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[s2 * SPS + tc * 16], acc[tc], 0, 0, 0);
+            if (kb + 1 < NP / 16) {
+                double *An = Apan + (buf ^ 1) * G::A_DOUBLES;
+                *reinterpret_cast<double2 *>(An + lA0) = sa0;
+                *reinterpret_cast<double2 *>(An + lA1) = sa1;
+            }
+            __syncthreads();
+        }
+        // one power-of-two scale for the slab: exponent of its largest entry
+        double mx = 0.0;
+#pragma unroll
+        for (int tc = 0; tc < TCS; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = acc[tc][q];
+                mx = (v > mx || v != v) ? v : mx;
+            }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double o = __shfl_xor(mx, m, 64);
+            mx = (o > mx || o != o) ? o : mx;
+        }
+        if (lane == 0) atomicMax(&smax[which], (unsigned long long)__double_as_longlong(mx));
+        __syncthreads();   // also: every wavefront has finished reading the slab
+        const double m = __longlong_as_double((long long)smax[which]);
+        if (tid == 0) smax[which ^ 1] = 0ull;
+        which ^= 1;
+        int e = 0;
+        (void)frexp(m, &e);
+        e = (m > 0.0 && m < INFINITY) ? e : 0;
+#pragma unroll
+        for (int tc = 0; tc < TCS; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) slab[(size_t)(row0 + lg + 4 * q) * SPS + tc * 16 + lm] = ldexp(acc[tc][q], -e);
+        ex += cex[tok] + e;
+        __syncthreads();
     }
-    // results -> level 0: operator block state-major [i][c] (N x PP0) or, for a first segment, the vector [i]
-    const uint32_t v0 = a.seg_vec0[blockIdx.x];
-    const size_t gv = (size_t)b * a.n_vecs_total + v0;
+    // results -> level 0: operator block state-major [i][c] (N x NP), or the vector [i] for a first segment
+    const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
     double *Pout = a.P + gv * NP;
     if (first) {
-        for (int i = tid; i < a.N; i += BIG_THREADS) Pout[i] = cur[(size_t)i * NP];
-        if (tid == 0) a.EX[gv] = (int)ex;
-    } else {
-        for (int idx = tid; idx < a.N * NP; idx += BIG_THREADS) {
-            const int i = idx / NP, c = idx - i * NP;
-            Pout[idx] = (c < a.N) ? cur[(size_t)i * NP + c] : 0.0;
+        if (bk.slab == 0) {
+            for (int i = tid; i < a.N; i += THREADS) Pout[i] = slab[i * SPS];
+            if (tid == 0) a.EX[gv] = (int)ex;
         }
-        for (int c = tid; c < a.N; c += BIG_THREADS) a.EX[gv + c] = (int)ex;
+    } else {
+        for (int idx = tid; idx < a.N * SC; idx += THREADS) {
+            const int i = idx / SC, c = idx - i * SC;
+            if (c0 + c < NP) Pout[(size_t)i * NP + c0 + c] = (c0 + c < a.N) ? slab[i * SPS + c] : 0.0;
+        }
+        for (int c = tid; c < SC; c += THREADS)
+            if (c0 + c < a.N) a.EX[gv + c0 + c] = (int)ex;
     }
 }
