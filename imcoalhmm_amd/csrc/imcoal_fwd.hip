@@ -75,6 +75,11 @@ struct DictDev {                                   // one trained dictionary + i
     uint8_t *d_order = nullptr;                    // merged tokens sorted by (depth, id)
     std::vector<uint8_t> order;                    // host copy of d_order
     std::vector<int> depth;                        // per token; raw symbols have depth 0
+    pid_t pid = 0;
+    ~DictDev()
+    {
+        if (pid == getpid()) { (void)hipFree(d_left); (void)hipFree(d_right); (void)hipFree(d_order); }
+    }
 };
 
 struct Ev3 { hipEvent_t a, b, c; };   // a: before propagate, b: after propagate, c: after stitch
@@ -198,6 +203,7 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
         if (it != g.dicts.end()) dd = it->second;
         else if (L >= DICT_TRAIN_MIN) {
             dd = std::make_shared<DictDev>();
+            dd->pid = g.pid;
             const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
             imc::train_dict(dd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64);
             dd->dict.id = g.next_dict_id++;
