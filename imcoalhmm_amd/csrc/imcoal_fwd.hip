@@ -444,7 +444,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     if (big) a_max = imc::kMaxAlphabet;
     else
         for (int A = 1; A <= imc::kMaxAlphabet; ++A)
-            if (kc->zip_lds(A) <= LDS_BUDGET) a_max = A;
+            if (kc->zip_lds(A) <= LDS_BUDGET || (kc->zip2 && g.kernel_pref != 1 && kc->zip2_lds(A) <= LDS_BUDGET)) a_max = A;
     // One dictionary level per dictionary: the deepest level is not always the best - every workgroup rebuilds
     // the operator table per evaluation ((A - S) dependent small products), which dominates on short inputs.
     // Estimate: table build + main loop with all 16-lane rows of the machine busy.
@@ -554,7 +554,8 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
                 if (std::getenv("IMC_DEBUG"))
                     std::fprintf(stderr, "[imc] plan: vector kernel seg %zu cost %.3g cycles; blocked kernel seg %zu slots %.0f cost %.3g cycles\n",
                                  seg_vec, cost_vec, seg_blk, slots, cost_blk);
-                if (g.kernel_pref == 2 || cost_blk < cost_vec) { gr.zip2 = true; gr.seglen = seg_blk; }
+                const bool vec_fits = !gr.zip || kc->zip_lds(gr.A) <= LDS_BUDGET;   // the table may only fit the blocked kernel
+                if (g.kernel_pref == 2 || cost_blk < cost_vec || !vec_fits) { gr.zip2 = true; gr.seglen = seg_blk; }
             }
         }
         if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);   // tests: force stitching
