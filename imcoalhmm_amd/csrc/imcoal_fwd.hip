@@ -540,15 +540,15 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
                 // a workgroup takes 32 consecutive segments of ONE chunk: rows are allocated per chunk in 32s
                 auto rows_used = [&](size_t sg) {
                     double r = 0.0;
-                    for (size_t L : lens) r += std::ceil(std::ceil((double)L / (double)sg) / 32.0) * 32.0;
+                    for (size_t L : lens) r += std::ceil(std::ceil((double)L / (double)sg) / Z2SLOTS) * Z2SLOTS;
                     return r;
                 };
                 for (int rounds = 1; rounds <= 16; ++rounds) {               // fill the machine's rows `rounds` times
-                    const double target = std::max(32.0, std::floor(rows * rounds / B));
+                    const double target = std::max((double)Z2SLOTS, std::floor(rows * rounds / B));
                     size_t sg = std::max<size_t>(16, round_up((size_t)std::ceil((double)total / target), 16));
                     for (int it = 0; it < 256 && rows_used(sg) > target; ++it) sg += 16;
                     const double used = rows_used(sg);
-                    const double c = std::ceil(used * B / rows) * (double)sg * 2.0 * step_cycles;
+                    const double c = std::ceil(used * B / rows) * (double)sg * (Z2WAVES / 4.0) * step_cycles;
                     if (c < cost_blk) { cost_blk = c; seg_blk = sg; slots = used; }
                 }
                 if (std::getenv("IMC_DEBUG"))
@@ -585,7 +585,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     std::vector<std::vector<std::pair<uint32_t, uint32_t>>> chunk_units(n_chunks);   // per chunk: (seg0, nsegs)
     for (int f = 0; f < n_chunks; ++f) {
         const Group &gr = p->groups[chunk_group[f]];
-        const uint32_t step = gr.zip2 ? 32u : 1u;
+        const uint32_t step = gr.zip2 ? (uint32_t)Z2SLOTS : 1u;
         for (uint32_t sid = chunk_seg[f]; sid < chunk_seg[f + 1]; sid += step)
             chunk_units[f].push_back({sid, std::min(step, chunk_seg[f + 1] - sid)});
     }

@@ -15,7 +15,11 @@
 #include "kernels_big.hpp"
 #include "kernels_zip.hpp"
 
-static constexpr int Z2WAVES = 8;   // wavefronts per workgroup (512 threads, 32 segments)
+#ifndef IMC_Z2WAVES
+#define IMC_Z2WAVES 8
+#endif
+static constexpr int Z2WAVES = IMC_Z2WAVES;   // wavefronts per workgroup
+static constexpr int Z2SLOTS = Z2WAVES * 4;    // segments (16-lane rows) per workgroup
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x)
@@ -37,31 +41,43 @@ template <int RB>
 struct Zip2Geom {
     static constexpr int NP = 4 * RB;
     static constexpr int NPS = NP + 2;   // operator row stride in LDS (doubles): rows of one grid column land on distinct banks
-    // the operator table doubles as the exchange area of the end-of-kernel fold (32 slots)
-    static constexpr int slots(int A) { return A > 32 ? A : 32; }
-    static constexpr size_t lds_bytes(int A) { return ((size_t)slots(A) * NP * NPS) * 8 + (size_t)((slots(A) + 1) & ~1) * 4 + 16; }
+    // the operator table doubles as the exchange area of the end-of-kernel fold (Z2SLOTS operators, unpadded rows)
+    static constexpr size_t op_doubles(int A)
+    {
+        return (size_t)A * NP * NPS > (size_t)Z2SLOTS * NP * NP ? (size_t)A * NP * NPS : (size_t)Z2SLOTS * NP * NP;
+    }
+    static constexpr int ints(int A) { return ((A > Z2SLOTS ? A : Z2SLOTS) + 1) & ~1; }
+    static constexpr size_t lds_bytes(int A) { return op_doubles(A) * 8 + (size_t)ints(A) * 4 + 16; }
 };
 
-// acc[ii][cc] += sum_jj C[row0+ii][j0+jj] * src[jj][cc]
-template <int RB, int NPS>
-__device__ __forceinline__ void zip2_block(double (&acc)[RB][RB], const double (&src)[RB][RB], const double *Crow)
+// acc[ii][cc] += sum_jj C[row0+ii][j0+jj] * src[jj][cc], where src is P itself (CTRL = 0) or the P block of
+// another lane of the grid column, fetched one row at a time by DPP row rotation (keeps only RB doubles of the
+// partner block live, which is what lets three wavefronts share a SIMD at N=20).
+template <int RB, int NPS, int CTRL>
+__device__ __forceinline__ void zip2_block(double (&acc)[RB][RB], const double (&P)[RB][RB], const double *Crow)
 {
 #pragma unroll
     for (int jj = 0; jj < RB; ++jj) {
+        double q[RB];
+#pragma unroll
+        for (int cc = 0; cc < RB; ++cc) {
+            if constexpr (CTRL == 0) q[cc] = P[jj][cc];
+            else q[cc] = dpp_f64<CTRL>(P[jj][cc]);
+        }
 #pragma unroll
         for (int ii = 0; ii < RB; ++ii) {
             const double c = Crow[ii * NPS + jj];
 #pragma unroll
-            for (int cc = 0; cc < RB; ++cc) acc[ii][cc] = fma(c, src[jj][cc], acc[ii][cc]);
+            for (int cc = 0; cc < RB; ++cc) acc[ii][cc] = fma(c, q[cc], acc[ii][cc]);
         }
     }
 }
 
-template <int RB, bool PRED>
+template <int RB, bool PRED, int NPS = Zip2Geom<RB>::NPS>
 __device__ __forceinline__ void zip2_step(double (&P)[RB][RB], const double *C, const int *cex, int tok, int rb,
                                           const int (&rbs)[3], bool act, int &ex)
 {
-    constexpr int NP = 4 * RB, NPS = Zip2Geom<RB>::NPS;
+    constexpr int NP = 4 * RB;
     const int ce = cex[tok];
     const double *Cz = C + (size_t)tok * (NP * NPS) + (size_t)(rb * RB) * NPS;
     double acc[RB][RB];
@@ -69,31 +85,10 @@ __device__ __forceinline__ void zip2_step(double (&P)[RB][RB], const double *C, 
     for (int ii = 0; ii < RB; ++ii)
 #pragma unroll
         for (int cc = 0; cc < RB; ++cc) acc[ii][cc] = 0.0;
-    zip2_block<RB, NPS>(acc, P, Cz + rb * RB);
-    {
-        double q[RB][RB];
-#pragma unroll
-        for (int jj = 0; jj < RB; ++jj)
-#pragma unroll
-            for (int cc = 0; cc < RB; ++cc) q[jj][cc] = dpp_f64<DPP_ROW_ROR4>(P[jj][cc]);
-        zip2_block<RB, NPS>(acc, q, Cz + rbs[0] * RB);
-    }
-    {
-        double q[RB][RB];
-#pragma unroll
-        for (int jj = 0; jj < RB; ++jj)
-#pragma unroll
-            for (int cc = 0; cc < RB; ++cc) q[jj][cc] = dpp_f64<DPP_ROW_ROR8>(P[jj][cc]);
-        zip2_block<RB, NPS>(acc, q, Cz + rbs[1] * RB);
-    }
-    {
-        double q[RB][RB];
-#pragma unroll
-        for (int jj = 0; jj < RB; ++jj)
-#pragma unroll
-            for (int cc = 0; cc < RB; ++cc) q[jj][cc] = dpp_f64<DPP_ROW_ROR12>(P[jj][cc]);
-        zip2_block<RB, NPS>(acc, q, Cz + rbs[2] * RB);
-    }
+    zip2_block<RB, NPS, 0>(acc, P, Cz + rb * RB);
+    zip2_block<RB, NPS, DPP_ROW_ROR4>(acc, P, Cz + rbs[0] * RB);
+    zip2_block<RB, NPS, DPP_ROW_ROR8>(acc, P, Cz + rbs[1] * RB);
+    zip2_block<RB, NPS, DPP_ROW_ROR12>(acc, P, Cz + rbs[2] * RB);
 #pragma unroll
     for (int ii = 0; ii < RB; ++ii)
 #pragma unroll
@@ -126,15 +121,15 @@ __device__ __forceinline__ void zip2_rescale(double (&P)[RB][RB], int &ex)
 }
 
 template <int RB>
-__global__ __launch_bounds__(Z2WAVES * 64, 2) void k_zpropagate2(BigArgs a)
+__global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate2(BigArgs a)
 {
     using Geo = Zip2Geom<RB>;
     constexpr int NP = Geo::NP, NPS = Geo::NPS, NT = Z2WAVES * 64;
     constexpr int EPT = (NP * NP + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *C = lds;                                                   // [A][NP][NPS]
-    int *cex = reinterpret_cast<int *>(C + (size_t)Geo::slots(a.A) * NP * NPS);    // [slots]
-    unsigned long long *smax = reinterpret_cast<unsigned long long *>(cex + ((Geo::slots(a.A) + 1) & ~1));   // [2]
+    int *cex = reinterpret_cast<int *>(C + Geo::op_doubles(a.A));    // [max(A, Z2SLOTS)]
+    unsigned long long *smax = reinterpret_cast<unsigned long long *>(cex + Geo::ints(a.A));   // [2]
 
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -202,7 +197,7 @@ __global__ __launch_bounds__(Z2WAVES * 64, 2) void k_zpropagate2(BigArgs a)
     const int q16 = lane & 15, rb = q16 >> 2, cb = q16 & 3;
     const int rbs[3] = {dpp_i32<DPP_ROW_ROR4>(rb), dpp_i32<DPP_ROW_ROR8>(rb), dpp_i32<DPP_ROW_ROR12>(rb)};
     const Z2Block blk = a.blocks[blockIdx.x];
-    const int slot = (tid >> 6) * 4 + (lane >> 4);          // 0..31 within the workgroup
+    const int slot = (tid >> 6) * 4 + (lane >> 4);          // 0..Z2SLOTS-1 within the workgroup
     const bool valid = slot < (int)blk.n;
     const uint32_t seg = blk.seg0 + (valid ? slot : 0);
     const SegDesc sd = a.segs[seg];
@@ -258,20 +253,20 @@ __global__ __launch_bounds__(Z2WAVES * 64, 2) void k_zpropagate2(BigArgs a)
     // ---- fold the workgroup's segments into one: P_0 <- P_{n-1} ... P_1 P_0 (binary tree through LDS) ----
     // The operator table is dead once every wavefront is here; its space becomes the exchange area, and a
     // fold step is an ordinary token step whose "token operator" is the partner slot's P.
-    for (int stride = 1; stride < 32; stride <<= 1) {
+    for (int stride = 1; stride < Z2SLOTS; stride <<= 1) {
         if ((int)blk.n <= stride) break;          // workgroup-uniform
         __syncthreads();                          // table (or previous level's exchange data) no longer read
         if (valid && (slot & stride) && !(slot & (stride - 1))) {   // this slot is a partner ("hi") at this level
-            double *dst = C + (size_t)slot * (NP * NPS) + (size_t)(rb * RB) * NPS + cb * RB;
+            double *dst = C + (size_t)slot * (NP * NP) + (size_t)(rb * RB) * NP + cb * RB;   // exchange rows are unpadded
 #pragma unroll
             for (int ii = 0; ii < RB; ++ii)
 #pragma unroll
-                for (int cc = 0; cc < RB; ++cc) dst[ii * NPS + cc] = P[ii][cc];
+                for (int cc = 0; cc < RB; ++cc) dst[ii * NP + cc] = P[ii][cc];
             if (q16 == 0) cex[slot] = ex;
         }
         __syncthreads();
         const bool act = valid && !(slot & (2 * stride - 1)) && slot + stride < (int)blk.n;
-        zip2_step<RB, true>(P, C, cex, act ? slot + stride : 0, rb, rbs, act, ex);
+        zip2_step<RB, true, NP>(P, C, cex, act ? slot + stride : 0, rb, rbs, act, ex);
         zip2_rescale<RB>(P, ex);
     }
 
