@@ -302,8 +302,15 @@ KernelChoice kChoices[] = {
 };
 constexpr int IMC_MAX_N = 192;
 
-KernelChoice *choose_kernel(int N)
+// MFMA GEMM-chain variants for 24 < N <= 64 (small workgroups, several per CU): used instead of the vector
+// kernels when a launch is dominated by operator segments (long chunks).
+KernelChoice kMidChoices[] = {make_big<2, 1>(), make_big<3, 1>(), make_big<4, 1>()};   // NP = 32, 48, 64
+
+KernelChoice *choose_kernel(int N, bool prefer_gemm)
 {
+    if (prefer_gemm && N > 24 && N <= 64)
+        for (auto &k : kMidChoices)
+            if (k.NP >= N) return &k;
     for (auto &k : kChoices)
         if (k.NP >= N) return &k;
     return nullptr;
@@ -433,7 +440,17 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             return IMC_OK;
         }
     }
-    KernelChoice *kc = choose_kernel(N);
+    // 24 < N <= 64: the GEMM-chain kernels beat the vector kernels by 5-100x when chunks are long enough to be
+    // cut into many operator segments; short-chunk / many-theta launches keep the vector kernels
+    bool prefer_gemm = g.kernel_pref == 2;
+    if (g.kernel_pref == 0 && N > 24 && N <= 64 && n_chunks > 0) {
+        double total = 0.0;
+        for (int f = 0; f < n_chunks; ++f) total += (double)chunks[f]->L;
+        bool tokens = g.compression != 0;   // on the raw column stream the vector kernel still wins up to N=40 (no padding to 16s)
+        for (int f = 0; f < n_chunks; ++f) tokens = tokens && chunks[f]->dict && chunks[f]->nsym == S;
+        prefer_gemm = total / n_chunks >= 2.0e5 && (tokens || N > 40);
+    }
+    KernelChoice *kc = choose_kernel(N, prefer_gemm);
     if (!kc) return fail(IMC_ERR_ARG, "N exceeds the largest built kernel (" + std::to_string(IMC_MAX_N) + ")");
     auto p = std::make_unique<Plan>();
     p->key = key; p->kc = kc; p->N = N; p->S = S; p->B = B; p->n_chunks = n_chunks;
@@ -511,7 +528,8 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             // one equal-length segment per CU is both balanced and the fewest operators for the stitch
             size_t total = 0;
             for (size_t L : lens) total += L;
-            const size_t target = std::max<size_t>(1, (size_t)g.cus / (size_t)B);
+            const size_t per_cu = std::max<size_t>(1, std::min<size_t>(LDS_BUDGET / kc->big_lds, (size_t)32 / (size_t)kc->G));
+            const size_t target = std::max<size_t>(1, (size_t)g.cus * per_cu / ((size_t)B * kc->big_nslab));
             gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
         } else {
             // vector kernel (one vector per lane group) ...

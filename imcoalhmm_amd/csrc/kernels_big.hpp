@@ -59,10 +59,10 @@ struct BigLds {
 
 template <int NT>
 __device__ __forceinline__ void big_gemm(const double *__restrict__ A, const double *__restrict__ B, int row0, int col0,
-                                         int tid, double *lds, v4f64 (&acc)[2][NT / 2])
+                                         int tid, double *lds, v4f64 (&acc)[1][NT])
 {
     using L = BigLds<NT>;
-    constexpr int NP = 16 * NT, TR = 2, TC = NT / 2, THREADS = NT * 64;
+    constexpr int NP = 16 * NT, TR = 1, TC = NT, THREADS = NT * 64;   // wavefront w computes tile-row w
     constexpr int APS = L::APS, BPS = L::BPS;
     const int lane = tid & 63, lm = lane & 15, lg = lane >> 4;
     // staging assignment: two double2 of the A panel (NP rows x 8 double2) and two of the B panel
@@ -130,9 +130,9 @@ __device__ __forceinline__ void big_gemm(const double *__restrict__ A, const dou
 // Workgroup-wide maximum of the (non-negative) accumulator entries -> exponent e with max in [2^(e-1), 2^e).
 // smax: two LDS slots used alternately (slot `which`); the other slot is cleared for the next call.
 template <int NT>
-__device__ __forceinline__ int big_exponent(const v4f64 (&acc)[2][NT / 2], unsigned long long *smax, int which, int tid)
+__device__ __forceinline__ int big_exponent(const v4f64 (&acc)[1][NT], unsigned long long *smax, int which, int tid)
 {
-    constexpr int TR = 2, TC = NT / 2;
+    constexpr int TR = 1, TC = NT;
     double mx = 0.0;
 #pragma unroll
     for (int tr = 0; tr < TR; ++tr)
@@ -159,10 +159,10 @@ __device__ __forceinline__ int big_exponent(const v4f64 (&acc)[2][NT / 2], unsig
 
 // Store the scaled accumulator tiles: D layout of v_mfma_f64_16x16x4_f64 is row = (lane>>4) + 4*reg, col = lane&15.
 template <int NT>
-__device__ __forceinline__ void big_store(double *__restrict__ D, int row0, int col0, int lane, const v4f64 (&acc)[2][NT / 2],
+__device__ __forceinline__ void big_store(double *__restrict__ D, int row0, int col0, int lane, const v4f64 (&acc)[1][NT],
                                           int e, int row_limit, int col_limit, size_t ld)
 {
-    constexpr int TR = 2, TC = NT / 2;
+    constexpr int TR = 1, TC = NT;
     const int lm = lane & 15, lg = lane >> 4;
 #pragma unroll
     for (int tr = 0; tr < TR; ++tr)
@@ -208,9 +208,9 @@ __global__ __launch_bounds__(NT * 64) void k_big_table_level(BigArgs a, const ui
     int *cex = a.cex + (size_t)b * a.A;
     if (tid < 2) smax[tid] = 0ull;
     __syncthreads();
-    const int row0 = (wave >> 1) * 32, col0 = (wave & 1) * 8 * NT;
+    const int row0 = wave * 16, col0 = 0;
     const int zl = a.tok_left[z], zr = a.tok_right[z];
-    v4f64 acc[2][NT / 2];
+    v4f64 acc[1][NT];
     big_gemm<NT>(Ct + (size_t)zr * NP * NP, Ct + (size_t)zl * NP * NP, row0, col0, tid, panels, acc);
     const int e = big_exponent<NT>(acc, smax, 0, tid);
     big_store<NT>(Ct + (size_t)z * NP * NP, row0, col0, lane, acc, e, NP, NP, NP);

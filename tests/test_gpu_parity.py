@@ -176,7 +176,7 @@ def test_text_file_constructor(oracle, hmm_params, example_pairs, tmp_path):
     assert len(g) == obs.size and g.forward(pi, T, E) == f.forward(pi, T, E)
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, 8, 10, 12, 16, 20, 23, 24, 28, 32, 37, 40, 70, 150])
+@pytest.mark.parametrize("n", [1, 3, 4, 8, 10, 12, 16, 20, 23, 24, 28, 32, 37, 40, 48, 49, 64, 70, 150])
 @pytest.mark.parametrize("mode", [2, 3], ids=["token-vector", "token-blocked"])
 def test_compressed_path_all_kernel_shapes(oracle, n, mode):
     """Both token kernels for every shape whose operator table fits LDS (mode 3 falls back to the vector
@@ -194,12 +194,32 @@ def test_compressed_path_all_kernel_shapes(oracle, n, mode):
             plan = _capi.last_plan()
         finally:
             set_seg(0)
-        assert plan["vector_tokens"] > 0                                      # the token path ran
-        assert n > 64 or plan["vector_columns"] > 0                           # ... and so did the raw-stream group
+        assert plan["vector_tokens"] > 0 or n > 40                            # the token path ran (N>40: no table fits LDS)
+        assert n > 64 or (mode == 3 and n > 24) or plan["vector_columns"] > 0 # ... and so did the raw-stream group
+        if mode == 3 and n > 24:
+            assert "k_big_propagate" in plan["kernels"]                       # GEMM-chain kernels for 24 < N <= 64
         for c, g in zip(chunks, got):
             want = oracle.forward_scaled(pi, T, E, c)
             assert rel_err(g, want) < TOL, (n, seg, c.size, g, want)
     set_zip(1)
+
+
+@pytest.mark.parametrize("n", [25, 32, 33, 48, 57, 64])
+def test_mid_size_gemm_chain_on_raw_stream(oracle, n):
+    """24 < N <= 64 with the MFMA GEMM-chain kernels pinned (mode 5), raw symbol stream, forced stitching."""
+    set_zip(5)
+    pi, T, E = synth.random_hmm(n, 3, seed=900 + n, stay=0.97)
+    chunks = [compressible(L, seed=n * 7 + k) for k, L in enumerate((3000, 17, 700))]
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    try:
+        set_seg(64)
+        got = forward_chunks_batch([f.handle for f in fw], pi[None], T[None], E[None], per_chunk=True)[0]
+        assert "k_big_propagate" in _capi.last_plan()["kernels"]
+    finally:
+        set_seg(0)
+        set_zip(1)
+    for c, g in zip(chunks, got):
+        assert rel_err(g, oracle.forward_scaled(pi, T, E, c)) < TOL, (n, c.size)
 
 
 def test_compression_off_uses_percolumn_kernel(oracle, hmm_params):
