@@ -1,0 +1,52 @@
+"""Seeded randomized sweep over the whole dispatch space: N, alphabet, chunk mixes (empty / tiny / long,
+compressible or not), stream + kernel modes, forced segment lengths and batch sizes - every value checked
+against the CPU oracle.  Catches dispatch/planning bugs that the per-kernel tests cannot."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from imcoalhmm_amd import Forwarder, _capi, synth
+from imcoalhmm_amd.hmm import forward_chunks_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _chunk(rng, nsym, L):
+    if L == 0:
+        return np.zeros(0, dtype=np.uint8)
+    if rng.random() < 0.6:                       # compressible: long runs of symbol 0
+        p = np.full(nsym, 0.08 / max(nsym - 1, 1)); p[0] = 0.92
+        return rng.choice(nsym, size=L, p=p / p.sum()).astype(np.uint8)
+    return rng.integers(0, nsym, size=L).astype(np.uint8)
+
+
+@pytest.mark.parametrize("case", range(150))
+def test_random_dispatch(oracle, case):
+    rng = np.random.default_rng(1000 + case)
+    L = _capi.lib()
+    n = int(rng.choice([1, 2, 3, 5, 8, 10, 13, 16, 20, 22, 24, 27, 32, 40, 47, 64, 65, 90, 128, 150, 192]))
+    nsym = int(rng.choice([2, 3, 3, 3, 4, 7]))
+    mode = int(rng.integers(0, 6))
+    seg = int(rng.choice([0, 0, 16, 48, 256, 1000]))
+    B = int(rng.choice([1, 1, 2, 3]))
+    heavy = n > 64
+    lens = [int(x) for x in rng.choice([0, 1, 5, 16, 17, 100, 999, 4096, 5000, 20000 if heavy else 60000,
+                                       9000 if heavy else 250000], size=int(rng.integers(1, 5)))]
+    hmms = [synth.random_hmm(n, nsym, seed=case * 10 + b, stay=float(rng.choice([0.5, 0.9, 0.999]))) for b in range(B)]
+    chunks = [_chunk(rng, nsym, x) for x in lens]
+    try:
+        _capi.check(L.imc_set_compression(mode))
+        _capi.check(L.imc_dictionary_reset())
+        _capi.check(L.imc_set_segment_length(seg))
+        fw = [Forwarder.from_array(c, nsym) for c in chunks]
+        got = forward_chunks_batch([f.handle for f in fw], np.stack([h[0] for h in hmms]), np.stack([h[1] for h in hmms]),
+                                   np.stack([h[2] for h in hmms]), per_chunk=True)
+        kernels = _capi.last_plan()["kernels"]
+    finally:
+        L.imc_set_compression(1)
+        L.imc_set_segment_length(0)
+    for b in range(B):
+        for f, c in enumerate(chunks):
+            want = oracle.forward_scaled(*hmms[b], c)
+            g = got[b, f]
+            assert (g == 0.0 and want == 0.0) or rel_err(g, want) < 1e-11, (case, n, nsym, mode, seg, B, lens, kernels, b, f, g, want)
