@@ -53,3 +53,24 @@ def test_forwarders_built_in_forked_children(tmp_path, oracle, hmm_params, examp
     for got, key in ((a, "iso10_t0"), (b, "iso10_t1")):
         want = oracle.forward_scaled(*hmm_params(key), obs)
         assert abs(got - want) / abs(want) < 1e-11
+
+
+def test_concurrent_calls_from_threads(oracle, hmm_params, example_pairs):
+    """The Python shim releases the GIL inside the C call; the library serialises calls with one mutex.  Four
+    threads hammering different Forwarders / models must each get their own correct value."""
+    from concurrent.futures import ThreadPoolExecutor
+    from imcoalhmm_amd import Forwarder
+    jobs = []
+    for k, (pname, mkey) in enumerate([("hg18__pantro2", "iso10_t0"), ("hg18__bonobo", "iso20_t0"),
+                                       ("pantro2__bonobo", "im20_t0"), ("hg18__ponabe2", "iso20_t2")]):
+        obs = example_pairs[pname]
+        jobs.append((Forwarder.from_array(obs, 3), hmm_params(mkey), oracle.forward_scaled(*hmm_params(mkey), obs)))
+
+    def work(j):
+        f, (pi, T, E), want = jobs[j % 4]
+        vals = [f.forward(pi, T, E) for _ in range(25)]
+        return max(abs(v - want) / abs(want) for v in vals), len(set(vals))
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        res = list(ex.map(work, range(8)))
+    assert all(err < 1e-11 and distinct == 1 for err, distinct in res), res
