@@ -104,6 +104,7 @@ struct Ctx {
 } g;
 
 void drop_plans();
+void reset_kernel_attributes();
 
 int ensure_ctx()
 {
@@ -314,6 +315,12 @@ KernelChoice *choose_kernel(int N, bool prefer_gemm)
     for (auto &k : kChoices)
         if (k.NP >= N) return &k;
     return nullptr;
+}
+
+void reset_kernel_attributes()
+{
+    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = false;
+    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = false;
 }
 
 // ---- launch plan ----------------------------------------------------------------------------------
@@ -991,6 +998,7 @@ int imc_set_device(int device)
         g.dicts.clear();
         (void)hipStreamDestroy(g.stream);
         g.ready = false;
+        reset_kernel_attributes();   // the dynamic-LDS opt-in is per device
     }
     g.device = device;
     return ensure_ctx();
