@@ -74,3 +74,22 @@ def test_concurrent_calls_from_threads(oracle, hmm_params, example_pairs):
     with ThreadPoolExecutor(max_workers=4) as ex:
         res = list(ex.map(work, range(8)))
     assert all(err < 1e-11 and distinct == 1 for err, distinct in res), res
+
+
+def test_integration_md_stub_is_valid(tmp_path, oracle, hmm_params, example_pairs):
+    """The ctypes stub INTEGRATION.md proposes for src/IMCoalHMM/hmm.py must actually work against the library."""
+    import re
+    from imcoalhmm_amd import _capi
+    md = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    code = re.search(r"## Option B.*?```python\n(.*?)```", md, flags=re.S).group(1)
+    os.environ["IMCOAL_FWD_LIB"] = _capi.LIB_PATH
+    ns = {}
+    exec(compile(code, "INTEGRATION.md:OptionB", "exec"), ns)
+    obs = example_pairs["hg18__pantro2"]
+    path = tmp_path / "pair.txt"
+    path.write_text(" ".join(str(int(s)) for s in obs) + " ")
+    f = ns["Forwarder"](str(path), NSYM=3)
+    pi, T, E = hmm_params("iso10_t0")
+    got = f.forward(np.matrix(pi), np.matrix(T), np.matrix(E))      # the reference's model layer returns numpy.matrix
+    want = oracle.forward_scaled(pi, T, E, obs)
+    assert abs(got - want) / abs(want) < 1e-11
