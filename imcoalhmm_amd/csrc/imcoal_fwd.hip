@@ -334,7 +334,7 @@ struct Group {             // one propagate launch
     BigBlock *d_big_blocks = nullptr;
     uint32_t *d_seg_ids = nullptr, *d_seg_out = nullptr;
     Z2Block *d_blocks = nullptr;
-    double *d_Ctab = nullptr, *d_scratch = nullptr;
+    double *d_Ctab = nullptr;
     int *d_cex = nullptr;
     bool zip = false;
     int level = -1, A = 0;
@@ -384,7 +384,7 @@ struct Plan {
         if (graph) (void)hipGraphExecDestroy(graph);
         (void)hipFree(d_segs); (void)hipFree(d_vecs); (void)hipFree(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_seg_out); (void)hipFree(gr.d_blocks); (void)hipFree(gr.d_big_blocks); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_scratch); (void)hipFree(gr.d_cex); }
+        for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_seg_out); (void)hipFree(gr.d_blocks); (void)hipFree(gr.d_big_blocks); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_cex); }
         (void)hipFree(d_params); (void)hipFree(d_out);
         (void)hipHostFree(h_params); (void)hipHostFree(h_out);
     }
@@ -828,7 +828,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.n_group_segs = (uint32_t)gr.seg_ids.size(); ba.n_vecs_total = p->n_vecs;
             ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
-            ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex; ba.scratch = nullptr;
+            ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
             hipLaunchKernelGGL(kc->big_table_raw, dim3((unsigned)S, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
@@ -869,7 +869,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.n_group_segs = (uint32_t)gr.blocks.size(); ba.n_vecs_total = p->n_vecs;
             ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
-            ba.Ctab = nullptr; ba.cex = nullptr; ba.scratch = nullptr;
+            ba.Ctab = nullptr; ba.cex = nullptr;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
             if (!kc->zip2_attr_set) {
                 HIP_TRY(hipFuncSetAttribute((const void *)kc->zip2, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -1,16 +1,15 @@
-// kernels_big.hpp - forward propagate for large state counts (64 < N <= 192).  Included by imcoal_fwd.hip.
+// kernels_big.hpp - forward propagate as a chain of dense N x N products on the matrix cores.  Included by
+// imcoal_fwd.hip.  Used for 64 < N <= 192 and, when chunks are long, for 24 < N <= 64.
 //
-// For N ~ 150 neither the N x N operators (180 KB each) nor a segment's transfer operator fit a CU's
-// LDS or one wavefront's registers, and the work per token step, P <- C_tok * P (N x N by N x N), is a
-// genuine dense fp64 GEMM.  This is the one place where the matrix cores are the right tool
-// ("MFMA becomes relevant only if the N^3 transfer-operator formulation is adopted"):
-// one workgroup owns one segment; with NT = NP/16 tiles per dimension its NT wavefronts form an (NT/2) x 2
-// grid, each computing a 32 x (8 NT) block of P_new as 2 x NT/2 accumulator tiles of
-// v_mfma_f64_16x16x4_f64 (<= 12 tiles = 96 accumulator registers, so 2-3 wavefronts fit per SIMD).  The A
-// fragments (rows of C_tok) and B fragments (rows of P_old) are loaded straight from L1/L2-resident global
-// memory into registers; neither LDS nor HBM is a limit.
-// P ping-pongs between two global scratch buffers of the workgroup; every step is rescaled by one exact
-// power of two (the exponent of the largest entry).
+// For N ~ 150 neither the N x N operators (180 KB each) nor a segment's transfer operator fit one wavefront's
+// registers, and the work per token step, P <- C_tok * P (N x N by N x N), is a genuine dense fp64 GEMM.  This is
+// the one place where the matrix cores are the right tool ("MFMA becomes relevant only if the
+// N^3 transfer-operator formulation is adopted"): v_mfma_f64_16x16x4_f64 tiles, NP = 16 NT.
+//   * k_big_table_raw / k_big_table_level build the per-evaluation operator table in global memory (L2-resident),
+//     one launch per dictionary depth; big_gemm is their workgroup-wide product (k panels staged through LDS).
+//   * k_big_propagate keeps a column slab of P resident in LDS for the whole launch and streams only the token
+//     operator's A panels; see the comment above the kernel.
+// Every step is rescaled by one exact power of two (the exponent of the largest entry).
 #pragma once
 #include "kernels_plain.hpp"
 
@@ -36,7 +35,6 @@ struct BigArgs {
     const uint8_t *tok_left, *tok_right;
     double *Ctab;                 // [B][A][NP][NP] operator table (row-major, zero padded)
     int *cex;                     // [B][A] power-of-two exponents of the table entries
-    double *scratch;              // unused (P lives in LDS slabs)
     double *P;                    // level-0 results (see kernels_stitch.hpp for the layout)
     int *EX;
 };
