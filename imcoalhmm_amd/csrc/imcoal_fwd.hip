@@ -271,6 +271,7 @@ struct KernelChoice {
     void (*zip2)(BigArgs);         // register-blocked token kernel (NP = 4 RB <= 24), else null
     size_t (*zip2_lds)(int);
     bool zip2_attr_set;
+    bool plain_attr_set = false;
 };
 
 template <int R, int G, int MW>
@@ -319,8 +320,8 @@ KernelChoice *choose_kernel(int N, bool prefer_gemm)
 
 void reset_kernel_attributes()
 {
-    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = false;
-    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = false;
+    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = k.plain_attr_set = false;
+    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = k.plain_attr_set = false;
 }
 
 // ---- launch plan ----------------------------------------------------------------------------------
@@ -897,6 +898,12 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             const uint32_t vpb = (uint32_t)(WPB * kc->VPW);
             dim3 grid((gr.n_vecs + vpb - 1) / vpb, (unsigned)B);
             const size_t lds = ((size_t)WPB * kc->VPW * NP + (size_t)S * NP) * 8;
+            if (lds > LDS_BUDGET) return fail(IMC_ERR_ARG, "emission table (S x N) too large for LDS");
+            if (lds > 48 * 1024 && !kc->plain_attr_set) {   // large alphabets: opt in to > 64 KB of dynamic LDS
+                HIP_TRY(hipFuncSetAttribute((const void *)kc->plain, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)LDS_BUDGET));
+                kc->plain_attr_set = true;
+            }
             hipLaunchKernelGGL(kc->plain, grid, dim3(WPB * 64), lds, stream, a);
             note("k_propagate<" + std::to_string(kc->R) + "," + std::to_string(kc->G) + ">" + strm);
             lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B;

@@ -106,6 +106,14 @@ def test_alphabet_sizes(oracle, nsym):
     assert abs(got - want) < TOL * max(abs(want), 1.0)
 
 
+def test_large_alphabet_with_many_states(oracle):
+    """S=256 with N=40: the per-column kernel's emission table needs > 64 KB of LDS (opt-in attribute)."""
+    pi, T, E = synth.random_hmm(40, 256, seed=5, stay=0.9)
+    obs = np.random.default_rng(5).integers(0, 256, size=2000).astype(np.uint8)
+    got = Forwarder.from_array(obs, 256).forward(pi, T, E)
+    assert rel_err(got, oracle.forward_scaled(pi, T, E, obs)) < TOL
+
+
 def test_ragged_and_empty_chunks_sum(oracle, hmm_params, zipmode):
     """likelihood.py:33 semantics: each chunk restarts from pi, values summed left to right."""
     pi, T, E = hmm_params("iso20_t0")
