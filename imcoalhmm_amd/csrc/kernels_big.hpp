@@ -282,14 +282,23 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
     const int row0 = wave * 16;
     long long ex = 0;
     int which = 0;
-    for (int t = first ? 1 : 0; t < len; ++t) {
+    // the first A panel of the NEXT token is fetched while the current step finishes (exponent, write-back),
+    // so no step starts with an exposed L2 round trip
+    const int t_begin = first ? 1 : 0;
+    const size_t aoff0 = (size_t)ar0 * NP + 2 * ac0, aoff1 = (size_t)ar1 * NP + 2 * ac1;
+    double2 sa0 = double2{0.0, 0.0}, sa1 = double2{0.0, 0.0};
+    if (t_begin < len) {
+        const double *A0 = Ct + (size_t)tokp[t_begin] * NP * NP;
+        sa0 = *reinterpret_cast<const double2 *>(A0 + aoff0);
+        sa1 = *reinterpret_cast<const double2 *>(A0 + aoff1);
+    }
+    for (int t = t_begin; t < len; ++t) {
         const int tok = tokp[t];
         const double *A = Ct + (size_t)tok * NP * NP;
-        const double *gA0 = A + (size_t)ar0 * NP + 2 * ac0, *gA1 = A + (size_t)ar1 * NP + 2 * ac1;
+        const double *gA0 = A + aoff0, *gA1 = A + aoff1;
         v4f64 acc[TCS];
 #pragma unroll
         for (int tc = 0; tc < TCS; ++tc) acc[tc] = v4f64{0.0, 0.0, 0.0, 0.0};
-        double2 sa0 = *reinterpret_cast<const double2 *>(gA0), sa1 = *reinterpret_cast<const double2 *>(gA1);
         *reinterpret_cast<double2 *>(Apan + lA0) = sa0;
         *reinterpret_cast<double2 *>(Apan + lA1) = sa1;
         __syncthreads();
@@ -316,6 +325,11 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
                 *reinterpret_cast<double2 *>(An + lA1) = sa1;
             }
             __syncthreads();
+        }
+        if (t + 1 < len) {   // prefetch the next token's first panel
+            const double *An = Ct + (size_t)tokp[t + 1] * NP * NP;
+            sa0 = *reinterpret_cast<const double2 *>(An + aoff0);
+            sa1 = *reinterpret_cast<const double2 *>(An + aoff1);
         }
         // one power-of-two scale for the slab: exponent of its largest entry
         double mx = 0.0;
