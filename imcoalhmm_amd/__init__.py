@@ -5,7 +5,7 @@ Host-side mirror of the reference's interface for the one accelerated path:
 both backed by the C-ABI HIP library ``libimcoal_fwd.so`` (include/imcoal_fwd.h).
 """
 from .hmm import Forwarder
-from .likelihood import Likelihood
+from .likelihood import Likelihood, maximum_likelihood_estimate
 
-__all__ = ["Forwarder", "Likelihood"]
+__all__ = ["Forwarder", "Likelihood", "maximum_likelihood_estimate"]
 __version__ = "0.1.0"

@@ -10,6 +10,7 @@ import ctypes
 import numpy as np
 
 from . import _capi, hmm
+from .likelihood import build_hmms
 
 
 def shard_indices(n_chunks, rank, world_size):
@@ -77,10 +78,5 @@ class DistributedLikelihood(object):
         out = np.full(len(thetas), -np.inf, dtype=np.float64)
         valid = [k for k, t in enumerate(thetas) if self.model.valid_parameters(t)]
         if valid:
-            hmms = [self.model.build_hidden_markov_model(thetas[k]) for k in valid]
-            vals = self.forward_params_batch(
-                np.stack([np.asarray(h[0], dtype=np.float64).reshape(-1) for h in hmms]),
-                np.stack([np.asarray(h[1], dtype=np.float64) for h in hmms]),
-                np.stack([np.asarray(h[2], dtype=np.float64) for h in hmms]))
-            out[valid] = vals
+            out[valid] = self.forward_params_batch(*build_hmms(self.model, [thetas[k] for k in valid]))
         return out

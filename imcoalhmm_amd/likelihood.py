@@ -11,6 +11,23 @@ import numpy as np
 from . import hmm
 
 
+def build_hmms(model, thetas):
+    """Stacked float64 ``(pis[B,N], Ts[B,N,N], Es[B,N,S])`` for a list of parameter points.
+
+    Uses ``model.build_batch`` when the model has one (imcoalhmm_amd.models), otherwise one
+    ``build_hidden_markov_model`` call per point (the reference's model classes, model.py:44-49).
+    """
+    if hasattr(model, "build_batch"):
+        pis, Ts, Es = model.build_batch(thetas)
+    else:
+        hmms = [model.build_hidden_markov_model(t) for t in thetas]
+        pis = np.stack([np.asarray(h[0], dtype=np.float64).reshape(-1) for h in hmms])
+        Ts = np.stack([np.asarray(h[1], dtype=np.float64) for h in hmms])
+        Es = np.stack([np.asarray(h[2], dtype=np.float64) for h in hmms])
+    return (np.ascontiguousarray(pis, dtype=np.float64), np.ascontiguousarray(Ts, dtype=np.float64),
+            np.ascontiguousarray(Es, dtype=np.float64))
+
+
 class Likelihood(object):
     """Combining model and data (likelihood.py:8-33)."""
 
@@ -46,15 +63,38 @@ class Likelihood(object):
         valid = [k for k, t in enumerate(thetas) if self.model.valid_parameters(t)]
         if not valid:
             return out
-        hmms = [self.model.build_hidden_markov_model(thetas[k]) for k in valid]
+        pis, Ts, Es = build_hmms(self.model, [thetas[k] for k in valid])
         ours, all_ours = self._split()
         if all_ours:
-            pis = np.stack([np.asarray(h[0], dtype=np.float64).reshape(-1) for h in hmms])
-            Ts = np.stack([np.asarray(h[1], dtype=np.float64) for h in hmms])
-            Es = np.stack([np.asarray(h[2], dtype=np.float64) for h in hmms])
             vals = hmm.forward_chunks_batch([f.handle for f in ours], pis, Ts, Es)
         else:
-            vals = [sum(f.forward(*h) for f in self.forwarders) for h in hmms]
+            vals = [sum(f.forward(pis[b], Ts[b], Es[b]) for f in self.forwarders) for b in range(len(valid))]
         for k, v in zip(valid, vals):
             out[k] = v
         return out
+
+
+def maximum_likelihood_estimate(log_likelihood, initial_parameters, optimizer_method="Nelder-Mead",
+                                log_file=None, log_param_transform=lambda x: x):
+    """Maximise ``log_likelihood`` from ``initial_parameters`` with a scipy optimiser (likelihood.py:36-87).
+
+    Same arguments and return value (the arg-max as an ndarray) as the reference: bounded methods get
+    ``(0, None)`` bounds per parameter, every accepted iterate is written tab-separated to
+    ``log_file`` after ``log_param_transform``.
+    """
+    import scipy.optimize
+
+    callback = None
+    if log_file:
+        def callback(parameters):
+            log_file.write('\t'.join(str(p) for p in log_param_transform(parameters)) + '\n')
+
+    def negated(parameters):
+        return -log_likelihood(parameters)
+
+    kwargs = {}
+    if optimizer_method in ('Anneal', 'L-BFGS-B', 'TNC', 'SLSQP'):
+        kwargs['bounds'] = [(0, None)] * len(initial_parameters)
+    result = scipy.optimize.minimize(fun=negated, x0=initial_parameters, method=optimizer_method,
+                                     callback=callback, options={'disp': False}, **kwargs)
+    return result.x

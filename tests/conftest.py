@@ -26,6 +26,11 @@ def hmm_params():
 
 
 @pytest.fixture(scope="session")
+def hmm_params_file():
+    return np.load(os.path.join(GOLDEN, "hmm_params.npz"))
+
+
+@pytest.fixture(scope="session")
 def example_pairs():
     d = np.load(os.path.join(GOLDEN, "example_pairs.npz"))
     return {k: d[k] for k in d.files}

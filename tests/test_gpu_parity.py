@@ -306,3 +306,48 @@ def test_bad_arguments_raise(hmm_params):
     big = synth.random_hmm(193, 3, 1)
     with pytest.raises(ValueError):
         f.forward(*big)                      # N beyond the largest built kernel is refused loudly
+
+
+def test_config1_end_to_end_from_theta(hmm_params_file, example_pairs, golden_loglik):
+    """theta -> imcoalhmm_amd.models -> Likelihood -> device, against the golden cells whose (pi, T, E)
+    came from the reference's own model classes (scripts/isolation-model.py:82-100 call pattern)."""
+    from imcoalhmm_amd import models
+    set_zip(1)
+    fw = {k: Forwarder.from_array(v, 3) for k, v in example_pairs.items()}
+    cases = [("iso10_t0", models.IsolationModel(10)), ("iso20_t0", models.IsolationModel(20)),
+             ("im20_t0", models.IsolationMigrationModel(10, 10)), ("im150_t0", models.IsolationMigrationModel(75, 75))]
+    for mkey, model in cases:
+        theta = hmm_params_file[mkey + "_theta"]
+        for pname in ("hg18__pantro2", "bonobo__ponabe2"):
+            want = golden_loglik["%s|%s" % (pname, mkey)]["loglik"]
+            got = Likelihood(model, fw[pname])(theta)
+            assert rel_err(got, want) < 1e-10, (mkey, pname, got, want)
+    # all six pairs as one likelihood, a population of proposals, invalid points gated
+    model = models.IsolationModel(10)
+    ll = Likelihood(model, list(fw.values()))
+    theta = hmm_params_file["iso10_t0_theta"]
+    total = sum(golden_loglik["%s|iso10_t0" % p]["loglik"] for p in fw)
+    assert rel_err(ll(theta), total) < 1e-10
+    thetas = np.stack([theta, theta * 1.1, -theta, theta * 0.9])
+    vals = ll.batch(thetas)
+    assert rel_err(vals[0], total) < 1e-10 and vals[2] == -np.inf
+    assert rel_err(vals[1], ll(thetas[1])) < 1e-12 and rel_err(vals[3], ll(thetas[3])) < 1e-12
+
+
+def test_maximum_likelihood_estimate_improves(hmm_params_file, example_pairs):
+    """likelihood.py:36-87 driver: a short Nelder-Mead run from the script defaults must not end lower."""
+    import io
+    from imcoalhmm_amd import maximum_likelihood_estimate, models
+    set_zip(1)
+    ll = Likelihood(models.IsolationModel(10), Forwarder.from_array(example_pairs["hg18__pantro2"], 3))
+    theta0 = hmm_params_file["iso10_t0_theta"]
+    calls = []
+
+    def counted(theta):
+        calls.append(1)
+        return ll(np.asarray(theta)) if len(calls) < 60 else -1e300      # bound the run
+
+    log = io.StringIO()
+    best = maximum_likelihood_estimate(counted, theta0, log_file=log)
+    assert best.shape == theta0.shape and ll(best) >= ll(theta0)
+    assert len(log.getvalue().splitlines()[0].split("\t")) == 3
