@@ -266,6 +266,8 @@ struct KernelChoice {
     void (*big_table_raw)(BigArgs);
     void (*big_table_level)(BigArgs, const uint8_t *, int);
     void (*big_prop)(BigArgs, const BigBlock *);
+    void (*big_vec)(BigArgs, const BigBlock *, int, int);
+    int big_vec_waves;
     int big_nslab;
     size_t big_lds;
     void (*zip2)(BigArgs);         // register-blocked token kernel (NP = 4 RB <= 24), else null
@@ -279,7 +281,7 @@ KernelChoice make_kc()
 {
     constexpr int NP = R * G;
     KernelChoice k{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
-                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, false};
+                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, false};
     if constexpr (NP % 4 == 0 && NP <= 24) {
         k.zip2 = k_zpropagate2<NP / 4>;
         k.zip2_lds = &Zip2Geom<NP / 4>::lds_bytes;
@@ -292,7 +294,7 @@ KernelChoice make_big()
 {
     constexpr int NP = 16 * NT;   // NT wavefronts per workgroup
     return KernelChoice{0, NT, NP, 0, 1, nullptr, nullptr, nullptr, k_chain<NP, 0>, false, k_big_table_raw<NT>,
-                        k_big_table_level<NT>, k_big_propagate<NT, NSLAB>, NSLAB, BigSlab<NT, NSLAB>::bytes,
+                        k_big_table_level<NT>, k_big_propagate<NT, NSLAB>, k_big_vector<NT>, BigVec<NT>::WAVES, NSLAB, BigSlab<NT, NSLAB>::bytes,
                         nullptr, nullptr, false};
 }
 
@@ -328,6 +330,7 @@ void reset_kernel_attributes()
 
 struct Group {             // one propagate launch
     bool big = false;      // large-N GEMM-chain kernel (one workgroup per segment)
+    bool bigvec = false;   // ... every chunk is one segment: mat-vec chain kernel (k_big_vector), no operators
     bool zip2 = false;     // register-blocked token kernel (one 16-lane row per segment)
     std::vector<uint32_t> seg_ids, seg_out;   // big: segment ids and their level-0 vector index
     std::vector<Z2Block> blocks;              // zip2: one entry per workgroup
@@ -492,6 +495,11 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
                     const double gemm = 0.027 * n3 + 20000.0;
                     c_tab = ((o0->alphabet[l] - S) / 6.0 + 2.0) * gemm;
                     c_main = std::max(16.0, toks * B / (double)g.cus) * gemm;
+                    double lmax = 0.0;   // or the mat-vec chain kernel, when no chunk needs splitting
+                    for (int f : kv.second) lmax = std::max(lmax, (double)chunks[f]->ntok[l]);
+                    const double np2 = (double)kc->NP * kc->NP;
+                    const double c_vec = std::max(lmax * (np2 / 8.0 + 1500.0), toks * B / (double)g.cus * (np2 / 3.0));
+                    if (g.kernel_pref == 1 || (g.kernel_pref == 0 && c_vec < c_main)) c_main = c_vec;
                 } else {     // ~5200 cycles per row-step at N=20; every workgroup rebuilds the table
                     c_tab = (o0->alphabet[l] - S) * (400.0 + n3 / 64.0);
                     c_main = std::max(16.0, toks * B / ((double)g.cus * 32.0)) * 0.65 * n3;
@@ -539,6 +547,21 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             const size_t per_cu = std::max<size_t>(1, std::min<size_t>(LDS_BUDGET / kc->big_lds, (size_t)32 / (size_t)kc->G));
             const size_t target = std::max<size_t>(1, (size_t)g.cus * per_cu / ((size_t)B * kc->big_nslab));
             gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
+            // ... unless there are so many (chunk, parameter set) chains that no chunk needs splitting: then
+            // the mat-vec chain kernel streams NP^2 doubles per step instead of a GEMM (measured at N=150, 64 x 32
+            // chains: 8900 cycles per step per CU, i.e. ~12 TB/s of operator reads over the whole chip)
+            size_t lmax = 0;
+            for (size_t L : lens) lmax = std::max(lmax, L);
+            const double np2 = (double)kc->NP * kc->NP, per_cu_steps = (double)total * B / (double)g.cus;
+            const double cost_vec = std::max((double)lmax * (np2 / 8.0 + 1500.0), per_cu_steps * (np2 / 3.0));
+            const double cost_gemm = std::max(16.0, per_cu_steps) * (0.027 * np2 * kc->NP + 20000.0);
+            if (std::getenv("IMC_DEBUG"))
+                std::fprintf(stderr, "[imc] plan: GEMM chain seg %zu cost %.3g cycles; mat-vec chain cost %.3g cycles\n",
+                             gr.seglen, cost_gemm, cost_vec);
+            if (g.kernel_pref == 1 || (g.kernel_pref == 0 && cost_vec < cost_gemm)) {
+                gr.bigvec = true;
+                gr.seglen = std::max<size_t>(16, round_up(lmax, 16));
+            }
         } else {
             // vector kernel (one vector per lane group) ...
             double cost_vec = 0.0;
@@ -585,6 +608,8 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             }
         }
         if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);   // tests: force stitching
+        if (gr.bigvec)
+            for (size_t L : lens) gr.bigvec = gr.bigvec && L <= gr.seglen;
     }
     // ---- segments in chunk order ----
     std::vector<SegDesc> segs;
@@ -854,6 +879,15 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                     }
                     i0 = i1;
                 }
+            }
+            if (gr.bigvec) {
+                const unsigned grid = 8u * (unsigned)gr.big_blocks.size() * (unsigned)((B + 7) / 8);
+                hipLaunchKernelGGL(kc->big_vec, dim3(grid), dim3(kc->big_vec_waves * 64), 0, stream, ba,
+                                   (const BigBlock *)gr.d_big_blocks, (int)gr.big_blocks.size(), B);
+                note("k_big_vector<" + std::to_string(kc->G) + ">" + strm);
+                lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
+                HIP_TRY(hipGetLastError());
+                continue;
             }
             if (!kc->zip_attr_set) {   // (flag reused: dynamic LDS size of the large-N propagate kernel)
                 HIP_TRY(hipFuncSetAttribute((const void *)kc->big_prop, hipFuncAttributeMaxDynamicSharedMemorySize,

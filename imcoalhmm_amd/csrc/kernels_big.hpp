@@ -377,3 +377,124 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
             if (c0 + c < a.N) a.EX[gv + c0 + c] = (int)ex;
     }
 }
+
+// Mat-vec chain for plans in which every chunk is ONE segment (many chunks x parameter sets, e.g. 64 proposals x
+// 32 one-Mbp chunks at N = 150): no transfer operators are needed at all, so the work per token step drops from a
+// GEMM (2 NP^3 flops) to x <- C_tok x (2 NP^2) and the kernel is bound by streaming the token operator
+// (NP^2 x 8 B per step) from L2 / MALL / HBM.  One workgroup of 8 or 16 wavefronts per (chunk, parameter set):
+//   * 16 lanes share an operator row: lane lm takes k = lm + 16 j, so one load instruction of a wavefront covers four
+//     rows x 128 contiguous bytes; the 16 partial sums are folded with four DPP row rotations (no LDS);
+//   * x lives in LDS, double buffered; the power-of-two scale of step t is applied when step t+1 reads x, which
+//     leaves ONE barrier per step (three rotating slots hold the per-step maximum);
+//   * workgroup ids are dealt so that all chunks of one parameter set run on one XCD back to back: they share that
+//     set's operator table in the XCD's L2.
+template <int NT>
+struct BigVec {
+    // every pass covers 4 WAVES rows and the passes tile NP = 16 NT rows exactly; <= 48 operator doubles per lane
+    static constexpr int WAVES = NT == 3 ? 12 : 8;
+    static constexpr bool PIPELINED = NT <= 10;      // beyond that the double set of operator registers would spill
+};
+
+template <int NT>
+__global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a, const BigBlock *blocks, int n_blocks, int B)
+{
+    constexpr int BV_WAVES = BigVec<NT>::WAVES;
+    constexpr int NP = 16 * NT, THREADS = BV_WAVES * 64, ROWS_PER_PASS = BV_WAVES * 4;
+    constexpr int PASSES = NP / ROWS_PER_PASS;
+    static_assert(PASSES * ROWS_PER_PASS == NP, "passes must tile the operator rows exactly");
+    __shared__ double xs[2][NP];
+    __shared__ unsigned long long smax[3];
+    const int xcd = blockIdx.x & 7, turn = blockIdx.x >> 3;
+    const int b = xcd + 8 * (turn / n_blocks);
+    if (b >= B) return;
+    const BigBlock bk = blocks[turn % n_blocks];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
+    const SegDesc sd = a.segs[bk.seg];
+    const int len = (int)sd.len;
+    const uint8_t *tokp = sd.obs;
+    const double *pp = a.params + (size_t)b * a.pstride;
+    const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
+    const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
+    const int *cex = a.cex + (size_t)b * a.A;
+
+    const int tok0 = (int)tokp[0];
+    for (int k = tid; k < NP; k += THREADS) xs[0][k] = k < a.N ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
+    if (tid < 3) smax[tid] = 0ull;
+    __syncthreads();
+
+    // The operator rows of step t+1 do not depend on x: as soon as a pass has consumed its registers they are
+    // refilled with the same rows of the NEXT token's operator, so a full operator (NP^2 x 8 B) is always in
+    // flight and no step starts with an exposed memory round trip.
+    long long ex = 0;
+    int e_prev = 0, cur = 0, slot = 0;
+    int rowoff[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int row = ps * ROWS_PER_PASS + wave * 4 + lg;
+        rowoff[ps] = row * NP + lm;
+    }
+    double av[PASSES][NT];
+    int tok = len > 1 ? (int)tokp[1] : 0;
+    int tok_next = len > 2 ? (int)tokp[2] : tok;
+    if constexpr (BigVec<NT>::PIPELINED) {
+        const double *A = Ct + (size_t)tok * NP * NP;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) av[ps][j] = A[rowoff[ps] + 16 * j];
+    }
+    for (int t = 1; t < len; ++t) {
+        const double *An = Ct + (size_t)(BigVec<NT>::PIPELINED ? tok_next : tok) * NP * NP;
+        if constexpr (!BigVec<NT>::PIPELINED) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) av[ps][j] = An[rowoff[ps] + 16 * j];
+        }
+        const int tok_after = t + 2 < len ? (int)tokp[t + 2] : tok_next;
+        const double *xc = &xs[cur][lm];   // x of step t-1 as stored (before its scale): the scale is applied to the dot products
+        double mx = 0.0;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int row = ps * ROWS_PER_PASS + wave * 4 + lg;
+            double p = 0.0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) p = fma(av[ps][j], xc[16 * j], p);
+            __builtin_amdgcn_sched_barrier(0);     // refill the registers just consumed, not fresh ones
+            if constexpr (BigVec<NT>::PIPELINED) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) av[ps][j] = An[rowoff[ps] + 16 * j];   // (last step: a harmless reload)
+            }
+            p += dpp_f64<DPP_ROW_ROR8>(p);
+            p += dpp_f64<DPP_ROW_ROR4>(p);
+            p += dpp_f64<DPP_ROW_ROR2>(p);
+            p += dpp_f64<DPP_ROW_ROR1>(p);
+            p = ldexp(p, -e_prev);
+            if (lm == 0) xs[cur ^ 1][row] = p;
+            mx = (p > mx || p != p) ? p : mx;
+        }
+#pragma unroll
+        for (int m = 32; m >= 16; m >>= 1) {
+            const double o = __shfl_xor(mx, m, 64);
+            mx = (o > mx || o != o) ? o : mx;
+        }
+        if (lane == 0) atomicMax(&smax[slot], (unsigned long long)__double_as_longlong(mx));
+        const int next_slot = slot == 2 ? 0 : slot + 1;
+        if (tid == 0) smax[next_slot] = 0ull;      // last read two steps ago, next written after this step's barrier
+        __syncthreads();
+        const double m = __longlong_as_double((long long)smax[slot]);
+        int e = 0;
+        (void)frexp(m, &e);
+        e = (m > 0.0 && m < INFINITY) ? e : 0;
+        ex += cex[tok] + e;
+        e_prev = e;
+        cur ^= 1;
+        slot = next_slot;
+        tok = tok_next;
+        tok_next = tok_after;
+    }
+    const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
+    double *Pout = a.P + gv * NP;
+    for (int i = tid; i < a.N; i += THREADS) Pout[i] = ldexp(xs[cur][i], -e_prev);
+    if (tid == 0) a.EX[gv] = (int)ex;
+}

@@ -21,21 +21,6 @@
 static constexpr int Z2WAVES = IMC_Z2WAVES;   // wavefronts per workgroup
 static constexpr int Z2SLOTS = Z2WAVES * 4;    // segments (16-lane rows) per workgroup
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double x)
-{
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    // bound_ctrl with full row/bank masks: every lane receives data, so no pre-initialising v_mov of the destination
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ int dpp_i32(int x)
-{
-    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true);
-}
-static constexpr int DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128, DPP_ROW_ROR12 = 0x12c;
 
 template <int RB>
 struct Zip2Geom {

@@ -351,3 +351,49 @@ def test_maximum_likelihood_estimate_improves(hmm_params_file, example_pairs):
     best = maximum_likelihood_estimate(counted, theta0, log_file=log)
     assert best.shape == theta0.shape and ll(best) >= ll(theta0)
     assert len(log.getvalue().splitlines()[0].split("\t")) == 3
+
+
+@pytest.mark.parametrize("n", [70, 100, 150, 192])
+@pytest.mark.parametrize("mode", [2, 4], ids=["tokens", "raw"])
+def test_matvec_chain_kernel_large_n(oracle, n, mode):
+    """N > 64 with one segment per chunk (pinned by the 'vector' modes): the mat-vec chain kernel, batch of 3."""
+    set_zip(mode)
+    rng = np.random.default_rng(n)
+    hmms = [synth.random_hmm(n, 3, seed=40 * n + b, stay=0.9 + 0.03 * b) for b in range(3)]
+    pis, Ts, Es = (np.stack([h[k] for h in hmms]) for k in range(3))
+    lens = (33_000, 1, 2, 17, 5000, 40_000, 16, 4097, 900, 33, 2500)
+    chunks = [compressible(L, seed=n * 13 + k) for k, L in enumerate(lens)]
+    chunks[4][1000:1400] = 2                       # a long run of the rare symbol
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    try:
+        got = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+        plan = _capi.last_plan()
+    finally:
+        set_zip(1)
+    assert "k_big_vector" in plan["kernels"] and "k_big_propagate" not in plan["kernels"]
+    for b in range(3):
+        for k in rng.choice(len(chunks), size=5, replace=False) if n > 100 else range(len(chunks)):
+            want = oracle.forward_scaled(pis[b], Ts[b], Es[b], chunks[k])
+            assert rel_err(got[b][k], want) < TOL, (n, mode, b, k, got[b][k], want)
+
+
+@pytest.mark.parametrize("n", [32, 41, 64])
+def test_matvec_chain_kernel_mid_n_many_chunks(oracle, n):
+    """24 < N <= 64: with many long chunks x proposals the planner drops the transfer operators altogether."""
+    set_zip(1)
+    hmms = [synth.random_hmm(n, 3, seed=77 * n + b, stay=0.95) for b in range(2)]
+    pis, Ts, Es = (np.stack([h[k] for h in hmms]) for k in range(3))
+    chunks = [compressible(210_000 + 1000 * k, seed=n * 17 + k) for k in range(40)]
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    got = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+    plan = _capi.last_plan()
+    assert "k_big_vector" in plan["kernels"], plan["kernels"]
+    try:
+        set_zip(3, reset=False)                    # same data through the GEMM-chain kernels
+        ref = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+        assert "k_big_propagate" in _capi.last_plan()["kernels"]
+    finally:
+        set_zip(1)
+    assert np.max(np.abs(got / ref - 1)) < TOL
+    for b, k in ((0, 0), (1, 39)):
+        assert rel_err(got[b][k], oracle.forward_scaled(pis[b], Ts[b], Es[b], chunks[k])) < TOL
