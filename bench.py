@@ -191,11 +191,21 @@ def main():
         traffic = None
         try:
             with open(os.path.join(REPO, "profiles", "r01_traffic_pmc.json")) as fh:
-                rec = json.load(fh).get("%s|%d|%d" % (kernel_name, n_states, local_cols))
+                rec = json.load(fh).get("%s|%d|%d" % (kernel_name, n_states, local_cols)
+                                        + ("|B%d" % args.batch if args.batch > 1 else ""))
             if rec and world == 1:
                 traffic = rec["hbm_bytes_per_launch"]
         except (OSError, ValueError):
             pass
+        operator_stream = None
+        if "k_big_vector" in kernel_name and k_s > 0:
+            # the mat-vec chain kernel is bound by streaming one NP x NP operator per chain step from L2 / Infinity Cache
+            npad = 16 * ((n_states + 15) // 16)
+            op_bytes = float(plan["vector_tokens"]) * npad * npad * 8.0
+            operator_stream = {"bytes_per_launch": op_bytes, "achieved_gbs": op_bytes / k_s / 1e9,
+                               "hbm_side_gbs": (traffic / k_s / 1e9) if traffic else None,
+                               "ceilings_gbs": {"l2_shared_rows": 16800.0, "infinity_cache": 8600.0, "hbm": 8000.0},
+                               "note": "ceilings: MI355X_MICROARCH.md 'Indexed rows' table (chip-wide, measured)"}
         out = {
             "metric": "alignment columns/sec (forward pass), %d-state isolation HMM" % n_states,
             "value": cols_per_s,
@@ -219,7 +229,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": kernel_name, "kernel_ms": k_ms, "stitch_ms": ms_s.value / max(n_s.value, 1),
+                "kernel": kernel_name, "kernel_ms": k_ms, "operator_stream": operator_stream, "stitch_ms": ms_s.value / max(n_s.value, 1),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "north_star names the HBM roof, but with 1 B/column the path is fp64-VALU/latency bound; "
                         "see fp64_valu",

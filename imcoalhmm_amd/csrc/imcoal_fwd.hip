@@ -506,6 +506,11 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
                 }
                 if (c_tab + c_main < best) { best = c_tab + c_main; best_l = l; }
             }
+            if (const char *fl = std::getenv("IMC_FORCE_LEVEL")) {   // experiments only: pin the dictionary level index
+                const int l = std::atoi(fl);
+                const imc_obs *o0 = chunks[kv.second[0]];
+                if (l >= 0 && l < imc::kNumLevels && o0->alphabet[l] <= a_max && o0->alphabet[l] > o0->nsym && o0->d_tok[l]) best_l = l;
+            }
             dict_level[kv.first] = best_l;
         }
     }

@@ -382,8 +382,8 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
 // 32 one-Mbp chunks at N = 150): no transfer operators are needed at all, so the work per token step drops from a
 // GEMM (2 NP^3 flops) to x <- C_tok x (2 NP^2) and the kernel is bound by streaming the token operator
 // (NP^2 x 8 B per step) from L2 / MALL / HBM.  One workgroup of 8 or 16 wavefronts per (chunk, parameter set):
-//   * 16 lanes share an operator row: lane lm takes k = lm + 16 j, so one load instruction of a wavefront covers four
-//     rows x 128 contiguous bytes; the 16 partial sums are folded with four DPP row rotations (no LDS);
+//   * 16 lanes share an operator row: lane lm takes two adjacent k per 16-byte load, so one load instruction of a
+//     wavefront covers four rows x 256 contiguous bytes; the 16 partial sums are folded with four DPP row rotations (no LDS);
 //   * x lives in LDS, double buffered; the power-of-two scale of step t is applied when step t+1 reads x, which
 //     leaves ONE barrier per step (three rotating slots hold the per-step maximum);
 //   * workgroup ids are dealt so that all chunks of one parameter set run on one XCD back to back: they share that
@@ -402,7 +402,8 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     constexpr int NP = 16 * NT, THREADS = BV_WAVES * 64, ROWS_PER_PASS = BV_WAVES * 4;
     constexpr int PASSES = NP / ROWS_PER_PASS;
     static_assert(PASSES * ROWS_PER_PASS == NP, "passes must tile the operator rows exactly");
-    __shared__ double xs[2][NP];
+    constexpr int W = NT % 2 == 0 ? 2 : 1, NJ = NT / W;   // lane lm takes k = W lm + 16 W jj + (0..W-1): 16-byte loads when NT is even
+    __shared__ __attribute__((aligned(16))) double xs[2][NP];
     __shared__ unsigned long long smax[3];
     const int xcd = blockIdx.x & 7, turn = blockIdx.x >> 3;
     const int b = xcd + 8 * (turn / n_blocks);
@@ -431,40 +432,53 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         const int row = ps * ROWS_PER_PASS + wave * 4 + lg;
-        rowoff[ps] = row * NP + lm;
+        rowoff[ps] = row * NP + W * lm;
     }
     double av[PASSES][NT];
+#define BV_LOAD(ps_, src_)                                                                          \
+    do {                                                                                            \
+        _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                         \
+            if constexpr (W == 2) {                                                                 \
+                const double2 v_ = *reinterpret_cast<const double2 *>((src_) + rowoff[ps_] + 32 * jj); \
+                av[ps_][2 * jj] = v_.x;                                                             \
+                av[ps_][2 * jj + 1] = v_.y;                                                         \
+            } else {                                                                                \
+                av[ps_][jj] = (src_)[rowoff[ps_] + 16 * jj];                                        \
+            }                                                                                       \
+        }                                                                                           \
+    } while (0)
     int tok = len > 1 ? (int)tokp[1] : 0;
     int tok_next = len > 2 ? (int)tokp[2] : tok;
     if constexpr (BigVec<NT>::PIPELINED) {
         const double *A = Ct + (size_t)tok * NP * NP;
 #pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) av[ps][j] = A[rowoff[ps] + 16 * j];
+        for (int ps = 0; ps < PASSES; ++ps) BV_LOAD(ps, A);
     }
     for (int t = 1; t < len; ++t) {
         const double *An = Ct + (size_t)(BigVec<NT>::PIPELINED ? tok_next : tok) * NP * NP;
         if constexpr (!BigVec<NT>::PIPELINED) {
 #pragma unroll
-            for (int ps = 0; ps < PASSES; ++ps)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) av[ps][j] = An[rowoff[ps] + 16 * j];
+            for (int ps = 0; ps < PASSES; ++ps) BV_LOAD(ps, An);
         }
         const int tok_after = t + 2 < len ? (int)tokp[t + 2] : tok_next;
-        const double *xc = &xs[cur][lm];   // x of step t-1 as stored (before its scale): the scale is applied to the dot products
+        const double *xc = &xs[cur][W * lm];   // x of step t-1 as stored (before its scale): the scale is applied to the dot products
         double mx = 0.0;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = ps * ROWS_PER_PASS + wave * 4 + lg;
             double p = 0.0;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) p = fma(av[ps][j], xc[16 * j], p);
-            __builtin_amdgcn_sched_barrier(0);     // refill the registers just consumed, not fresh ones
-            if constexpr (BigVec<NT>::PIPELINED) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j) av[ps][j] = An[rowoff[ps] + 16 * j];   // (last step: a harmless reload)
+            for (int jj = 0; jj < NJ; ++jj) {
+                if constexpr (W == 2) {
+                    const double2 xv = *reinterpret_cast<const double2 *>(xc + 32 * jj);
+                    p = fma(av[ps][2 * jj], xv.x, p);
+                    p = fma(av[ps][2 * jj + 1], xv.y, p);
+                } else {
+                    p = fma(av[ps][jj], xc[16 * jj], p);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);     // refill the registers just consumed, not fresh ones
+            if constexpr (BigVec<NT>::PIPELINED) BV_LOAD(ps, An);   // (last step: a harmless reload)
             p += dpp_f64<DPP_ROW_ROR8>(p);
             p += dpp_f64<DPP_ROW_ROR4>(p);
             p += dpp_f64<DPP_ROW_ROR2>(p);
@@ -497,4 +511,5 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     double *Pout = a.P + gv * NP;
     for (int i = tid; i < a.N; i += THREADS) Pout[i] = ldexp(xs[cur][i], -e_prev);
     if (tid == 0) a.EX[gv] = (int)ex;
+#undef BV_LOAD
 }
