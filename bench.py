@@ -163,7 +163,7 @@ def main():
     lib.imc_profile_read(ctypes.byref(ms_p), ctypes.byref(ms_s), ctypes.byref(n_p), ctypes.byref(n_s))
     lib.imc_profile_enable(0)
     plan = _capi.last_plan()
-    ntok0, alpha0 = forwarders[0].compressed_length(plan["token_alphabet"] or 128) if plan["vector_tokens"] else (len(forwarders[0]), 3)
+    ntok0, alpha0 = forwarders[0].compressed_length(plan["token_alphabet"] or 256) if plan["vector_tokens"] else (len(forwarders[0]), 3)
 
     if world > 1:
         rdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev

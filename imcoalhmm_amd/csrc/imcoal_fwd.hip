@@ -198,7 +198,7 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
                     std::string("observation upload: ") + hipGetErrorString(e));
     }
     // ---- compression (the preprocess_raw_observations analogue, hmm.py:16) ----
-    if (g.compression && L >= ZIP_MIN_COLUMNS && nsym <= imc::kLevels[imc::kNumLevels - 1] / 2) {
+    if (g.compression && L >= ZIP_MIN_COLUMNS && nsym <= 64) {
         std::shared_ptr<DictDev> dd;
         auto it = g.dicts.find(nsym);
         if (it != g.dicts.end()) dd = it->second;

@@ -6,8 +6,9 @@
 // many columns), re-designed for the GPU kernel's constraints:
 //   * the dictionary must be small enough that every token's N x N operator stays resident in
 //     one CU's LDS, so it is built as an ORDERED merge list and the stream is kept at several
-//     "levels" (alphabet sizes 8/12/16/24/32/44/64/96/128): level A uses the first A-S merges.  The forward
-//     call picks the deepest level whose table fits LDS for the model's N;
+//     "levels" (alphabet sizes 8/12/16/24/32/44/64/96/128/192/256): level A uses the first A-S merges.  The forward
+//     call picks the level that minimises its cost model among those whose table fits LDS for the model's N
+//     (the large-N kernels keep their table in global memory and may use all 256 tokens);
 //   * one dictionary per process and alphabet is trained on the first sufficiently long chunk and
 //     reused for every later chunk, so that all chunks of a likelihood share one operator table;
 //   * position 0 of a chunk is never merged (it is consumed by pi .* E[:,o_0]).
@@ -24,9 +25,9 @@ namespace imc {
 
 // alphabet sizes at which the token stream is kept; dense enough that some level sits close under any LDS limit
 // (N=20: 44 tokens = 155 KB of operators, N=10: 96 tokens)
-constexpr int kLevels[] = {8, 12, 16, 24, 32, 44, 64, 96, 128};
-constexpr int kNumLevels = 9;
-constexpr int kMaxAlphabet = 128;
+constexpr int kLevels[] = {8, 12, 16, 24, 32, 44, 64, 96, 128, 192, 256};
+constexpr int kNumLevels = 11;
+constexpr int kMaxAlphabet = 256;   // token ids are bytes
 
 struct PairDict {
     int nsym = 0;                  // raw alphabet size S

@@ -99,7 +99,7 @@ class Forwarder(object):
     def __len__(self):
         return int(_capi.lib().imc_obs_length(self._h))
 
-    def compressed_length(self, alphabet_limit=128):
+    def compressed_length(self, alphabet_limit=256):
         """(tokens, alphabet) of the pair-compressed stream - the (new_obs, new_nsyms) of hmm.py:16."""
         used = ctypes.c_int(0)
         n = _capi.lib().imc_obs_compressed_length(self._h, int(alphabet_limit), ctypes.byref(used))
