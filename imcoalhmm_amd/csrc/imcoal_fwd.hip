@@ -437,6 +437,15 @@ size_t choose_seglen(const std::vector<size_t> &lens, int N, int B, int VPW, dou
     return best_seg;
 }
 
+// Cycles per chain step and CU of the mat-vec chain kernel (k_big_vector): NP^2 doubles streamed per step.
+// Measured at N=150, 2048 chains: ~NP^2/3 cycles while one parameter set's table stays within ~6 MB (its share of
+// an XCD's L2), growing by ~3 % per further MB as reads fall through to the Infinity Cache, up to the HBM rate.
+static double matvec_step_cycles(double np2, int alphabet)
+{
+    const double table_mb = (double)alphabet * np2 * 8.0 / 1.0e6;
+    return np2 / 3.0 * std::min(2.2, 1.0 + 0.03 * std::max(0.0, table_mb - 6.0));
+}
+
 int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, Plan **out)
 {
     std::vector<uint64_t> key;
@@ -498,7 +507,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
                     double lmax = 0.0;   // or the mat-vec chain kernel, when no chunk needs splitting
                     for (int f : kv.second) lmax = std::max(lmax, (double)chunks[f]->ntok[l]);
                     const double np2 = (double)kc->NP * kc->NP;
-                    const double c_vec = std::max(lmax * (np2 / 8.0 + 1500.0), toks * B / (double)g.cus * (np2 / 3.0));
+                    const double c_vec = std::max(lmax * (np2 / 8.0 + 1500.0), toks * B / (double)g.cus * matvec_step_cycles(np2, o0->alphabet[l]));
                     if (g.kernel_pref == 1 || (g.kernel_pref == 0 && c_vec < c_main)) c_main = c_vec;
                 } else {     // ~5200 cycles per row-step at N=20; every workgroup rebuilds the table
                     c_tab = (o0->alphabet[l] - S) * (400.0 + n3 / 64.0);
@@ -558,7 +567,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             size_t lmax = 0;
             for (size_t L : lens) lmax = std::max(lmax, L);
             const double np2 = (double)kc->NP * kc->NP, per_cu_steps = (double)total * B / (double)g.cus;
-            const double cost_vec = std::max((double)lmax * (np2 / 8.0 + 1500.0), per_cu_steps * (np2 / 3.0));
+            const double cost_vec = std::max((double)lmax * (np2 / 8.0 + 1500.0), per_cu_steps * matvec_step_cycles(np2, gr.A));
             const double cost_gemm = std::max(16.0, per_cu_steps) * (0.027 * np2 * kc->NP + 20000.0);
             if (std::getenv("IMC_DEBUG"))
                 std::fprintf(stderr, "[imc] plan: GEMM chain seg %zu cost %.3g cycles; mat-vec chain cost %.3g cycles\n",
