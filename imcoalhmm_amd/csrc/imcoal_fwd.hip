@@ -67,13 +67,16 @@ int fail(int code, const std::string &msg)
 constexpr size_t LDS_BUDGET = 160 * 1024 - 1024;   // bytes of LDS a compressed-path workgroup may use
 constexpr size_t ZIP_MIN_COLUMNS = 4096;           // shorter chunks are not worth compressing
 constexpr size_t DICT_TRAIN_MIN = 32768;           // first chunk at least this long trains the dictionary
-constexpr size_t DICT_TRAIN_MAX = 8u << 20;        // train on at most this prefix
+constexpr size_t DICT_TRAIN_MAX = 8u << 20;        // byte tokens (< 256): train on at most this prefix
+constexpr size_t DICT_WIDE_TRAIN_TOKENS = 1u << 19; // 16-bit tokens: train on at most this many byte-level tokens (~4e7 columns)
+constexpr size_t DICT_WIDE_MIN_COUNT = 6;          // ... in which a pair must occur this often
+constexpr size_t CTAB_BUDGET = (size_t)24 << 30;   // largest operator table (all parameter sets) a plan may allocate
 
 struct DictDev {                                   // one trained dictionary + its device copy
     imc::PairDict dict;
-    uint8_t *d_left = nullptr, *d_right = nullptr;
-    uint8_t *d_order = nullptr;                    // merged tokens sorted by (depth, id)
-    std::vector<uint8_t> order;                    // host copy of d_order
+    uint16_t *d_left = nullptr, *d_right = nullptr;
+    uint16_t *d_order = nullptr;                   // merged tokens sorted by (depth, id)
+    std::vector<uint16_t> order;                   // host copy of d_order
     std::vector<int> depth;                        // per token; raw symbols have depth 0
     pid_t pid = 0;
     ~DictDev()
@@ -150,6 +153,7 @@ struct imc_obs {
     uint8_t *d_sym;                        // L raw symbols + zero padding
     std::shared_ptr<DictDev> dict;         // null: not compressed
     uint8_t *d_tok[imc::kNumLevels];       // token streams per level (aliases allowed), null if none
+    bool wide[imc::kNumLevels];            // ... holding 16-bit ids (alphabets beyond 256)
     size_t ntok[imc::kNumLevels];
     int alphabet[imc::kNumLevels];
 };
@@ -190,7 +194,7 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
     o->nsym = nsym;
     o->L = L;
     o->d_sym = nullptr;
-    for (int l = 0; l < imc::kNumLevels; ++l) { o->d_tok[l] = nullptr; o->ntok[l] = 0; o->alphabet[l] = nsym; }
+    for (int l = 0; l < imc::kNumLevels; ++l) { o->d_tok[l] = nullptr; o->wide[l] = false; o->ntok[l] = 0; o->alphabet[l] = nsym; }
     hipError_t e = upload_padded(host, L, &o->d_sym);
     if (e != hipSuccess) {
         delete o;
@@ -207,20 +211,27 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
             dd->pid = g.pid;
             const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
             imc::train_dict(dd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64);
+            if (dd->dict.alphabet >= imc::kByteAlphabet) {   // 16-bit tokens: rounds over the whole chunk's byte-level stream
+                const size_t cols = std::min(L, DICT_WIDE_TRAIN_TOKENS * 96);   // a byte-level token covers ~60-100 columns
+                const std::vector<uint8_t> lvl256 = imc::encode_bytes(dd->dict, host, cols, nullptr);
+                const size_t nt = std::min(lvl256.size() - 1, DICT_WIDE_TRAIN_TOKENS);
+                imc::train_dict_wide(dd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), DICT_WIDE_MIN_COUNT);
+            }
             dd->dict.id = g.next_dict_id++;
-            hipError_t e2 = hipMalloc((void **)&dd->d_left, imc::kMaxAlphabet);
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&dd->d_right, imc::kMaxAlphabet);
-            if (e2 == hipSuccess) e2 = hipMemcpy(dd->d_left, dd->dict.left, imc::kMaxAlphabet, hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = hipMemcpy(dd->d_right, dd->dict.right, imc::kMaxAlphabet, hipMemcpyHostToDevice);
+            const size_t abytes = (size_t)dd->dict.alphabet * sizeof(uint16_t);
+            hipError_t e2 = hipMalloc((void **)&dd->d_left, abytes);
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&dd->d_right, abytes);
+            if (e2 == hipSuccess) e2 = hipMemcpy(dd->d_left, dd->dict.left.data(), abytes, hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(dd->d_right, dd->dict.right.data(), abytes, hipMemcpyHostToDevice);
             dd->depth.assign(dd->dict.alphabet, 0);
             for (int z = nsym; z < dd->dict.alphabet; ++z)
                 dd->depth[z] = 1 + std::max(dd->depth[dd->dict.left[z]], dd->depth[dd->dict.right[z]]);
-            for (int z = nsym; z < dd->dict.alphabet; ++z) dd->order.push_back((uint8_t)z);
+            for (int z = nsym; z < dd->dict.alphabet; ++z) dd->order.push_back((uint16_t)z);
             std::stable_sort(dd->order.begin(), dd->order.end(),
-                             [&](uint8_t x, uint8_t y) { return dd->depth[x] < dd->depth[y]; });
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&dd->d_order, imc::kMaxAlphabet);
+                             [&](uint16_t x, uint16_t y) { return dd->depth[x] < dd->depth[y]; });
+            if (e2 == hipSuccess) e2 = hipMalloc((void **)&dd->d_order, std::max<size_t>(abytes, 16));
             if (e2 == hipSuccess && !dd->order.empty())
-                e2 = hipMemcpy(dd->d_order, dd->order.data(), dd->order.size(), hipMemcpyHostToDevice);
+                e2 = hipMemcpy(dd->d_order, dd->order.data(), dd->order.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
             if (e2 != hipSuccess) {
                 obs_release(o);
                 delete o;
@@ -234,10 +245,13 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
             o->dict = dd;
             for (int l = 0; l < imc::kNumLevels; ++l) {
                 o->alphabet[l] = enc.alphabet[l];
-                o->ntok[l] = enc.streams[l].size();
-                if (l > 0 && enc.alphabet[l] == enc.alphabet[l - 1]) { o->d_tok[l] = o->d_tok[l - 1]; continue; }
+                o->ntok[l] = enc.length[l];
+                o->wide[l] = enc.is_wide[l];
+                if (l > 0 && enc.alphabet[l] == enc.alphabet[l - 1]) { o->d_tok[l] = o->d_tok[l - 1]; o->wide[l] = o->wide[l - 1]; continue; }
                 if (enc.alphabet[l] <= nsym) { o->d_tok[l] = nullptr; continue; }   // raw stream: use d_sym
-                hipError_t e3 = upload_padded(enc.streams[l].data(), enc.streams[l].size(), &o->d_tok[l]);
+                hipError_t e3 = enc.is_wide[l]
+                    ? upload_padded(reinterpret_cast<const uint8_t *>(enc.wide[l].data()), enc.length[l] * sizeof(imc::tok_t), &o->d_tok[l])
+                    : upload_padded(enc.bytes[l].data(), enc.length[l], &o->d_tok[l]);
                 if (e3 != hipSuccess) {
                     obs_release(o);
                     delete o;
@@ -264,7 +278,7 @@ struct KernelChoice {
     ChainFn chain;
     bool zip_attr_set;
     void (*big_table_raw)(BigArgs);
-    void (*big_table_level)(BigArgs, const uint8_t *, int);
+    void (*big_table_level)(BigArgs, const uint16_t *, int);
     void (*big_prop)(BigArgs, const BigBlock *);
     void (*big_vec)(BigArgs, const BigBlock *, int, int);
     int big_vec_waves;
@@ -496,13 +510,14 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             for (int l = 0; l < imc::kNumLevels; ++l) {
                 const imc_obs *o0 = chunks[kv.second[0]];
                 if (!(o0->alphabet[l] <= a_max && o0->alphabet[l] > o0->nsym && o0->d_tok[l])) continue;
+                if (big && (size_t)B * o0->alphabet[l] * kc->NP * kc->NP * 8 > CTAB_BUDGET) continue;   // table too large
                 double toks = 0.0;
                 for (int f : kv.second) toks += (double)chunks[f]->ntok[l];
                 const double n3 = (double)kc->NP * kc->NP * kc->NP;
                 double c_tab, c_main;   // cycles
                 if (big) {   // one GEMM per step per workgroup (~0.027 n^3 cycles measured at N=150), table built by depth
                     const double gemm = 0.027 * n3 + 20000.0;
-                    c_tab = ((o0->alphabet[l] - S) / 6.0 + 2.0) * gemm;
+                    c_tab = ((o0->alphabet[l] - S) / (double)g.cus + 12.0) * gemm;   // one workgroup per token, ~12 depth launches
                     c_main = std::max(16.0, toks * B / (double)g.cus) * gemm;
                     double lmax = 0.0;   // or the mat-vec chain kernel, when no chunk needs splitting
                     for (int f : kv.second) lmax = std::max(lmax, (double)chunks[f]->ntok[l]);
@@ -638,7 +653,9 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         const size_t K0 = (L + gr.seglen - 1) / gr.seglen;
         const size_t sl = round_up((L + K0 - 1) / K0, 16);   // equalised, multiple of 16
         for (size_t off = 0, k = 0; off < L; off += sl, ++k) {
-            segs.push_back(SegDesc{base + off, (uint32_t)std::min(sl, L - off), k == 0 ? 1u : 0u});
+            const bool wide = gr.zip && chunks[f]->wide[gr.level];
+            segs.push_back(SegDesc{base + off * (wide ? 2 : 1), (uint32_t)std::min(sl, L - off),
+                                   (k == 0 ? SEG_FIRST : 0u) | (wide ? SEG_WIDE : 0u)});
             seg_first.push_back(k == 0);
         }
     }
@@ -886,7 +903,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                         while (r1 < i1 && (int)dd.order[r1] < gr.A) ++r1;
                         if (r1 > r0) {
                             hipLaunchKernelGGL(kc->big_table_level, dim3((unsigned)(r1 - r0), (unsigned)B), dim3(kc->G * 64), 0,
-                                               stream, ba, (const uint8_t *)dd.d_order, (int)r0);
+                                               stream, ba, (const uint16_t *)dd.d_order, (int)r0);
                             HIP_TRY(hipGetLastError());
                         }
                         r0 = r1;

@@ -32,7 +32,7 @@ struct BigArgs {
     const double *params;         // per parameter set: pi[PP] | Tp[PP*PP] | Et[S*PP]   (PP = params' padding)
     size_t pstride;
     int PP;
-    const uint8_t *tok_left, *tok_right;
+    const uint16_t *tok_left, *tok_right;
     double *Ctab;                 // [B][A][NP][NP] operator table (row-major, zero padded)
     int *cex;                     // [B][A] power-of-two exponents of the table entries
     double *P;                    // level-0 results (see kernels_stitch.hpp for the layout)
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_table_raw(BigArgs a)
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT * 64) void k_big_table_level(BigArgs a, const uint8_t *order, int first)
+__global__ __launch_bounds__(NT * 64) void k_big_table_level(BigArgs a, const uint16_t *order, int first)
 {
     constexpr int NP = 16 * NT;
     __shared__ unsigned long long smax[2];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
     const int b = blockIdx.y;
     const BigBlock bk = blocks[blockIdx.x];
     const SegDesc sd = a.segs[bk.seg];
-    const bool first = sd.first != 0;
+    const bool first = (sd.first & SEG_FIRST) != 0, wide = (sd.first & SEG_WIDE) != 0;
     const int len = (int)sd.len;
     const uint8_t *tokp = sd.obs;
     const int c0 = (int)bk.slab * SC;                // first global column of this slab
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
     const int *cex = a.cex + (size_t)b * a.A;
 
     // initial slab: identity columns, or (first segment, slab 0) column 0 = pi .* E[:,o_0]
-    const int tok0 = first ? (int)tokp[0] : 0;
+    const int tok0 = first ? seg_token(tokp, wide, 0) : 0;
     for (int idx = tid; idx < NP * SC; idx += THREADS) {
         const int k = idx / SC, c = idx - k * SC;
         double v;
@@ -288,12 +288,12 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
     const size_t aoff0 = (size_t)ar0 * NP + 2 * ac0, aoff1 = (size_t)ar1 * NP + 2 * ac1;
     double2 sa0 = double2{0.0, 0.0}, sa1 = double2{0.0, 0.0};
     if (t_begin < len) {
-        const double *A0 = Ct + (size_t)tokp[t_begin] * NP * NP;
+        const double *A0 = Ct + (size_t)seg_token(tokp, wide, t_begin) * NP * NP;
         sa0 = *reinterpret_cast<const double2 *>(A0 + aoff0);
         sa1 = *reinterpret_cast<const double2 *>(A0 + aoff1);
     }
     for (int t = t_begin; t < len; ++t) {
-        const int tok = tokp[t];
+        const int tok = seg_token(tokp, wide, t);
         const double *A = Ct + (size_t)tok * NP * NP;
         const double *gA0 = A + aoff0, *gA1 = A + aoff1;
         v4f64 acc[TCS];
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
             __syncthreads();
         }
         if (t + 1 < len) {   // prefetch the next token's first panel
-            const double *An = Ct + (size_t)tokp[t + 1] * NP * NP;
+            const double *An = Ct + (size_t)seg_token(tokp, wide, t + 1) * NP * NP;
             sa0 = *reinterpret_cast<const double2 *>(An + aoff0);
             sa1 = *reinterpret_cast<const double2 *>(An + aoff1);
         }
@@ -412,13 +412,14 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
     const SegDesc sd = a.segs[bk.seg];
     const int len = (int)sd.len;
+    const bool wide = (sd.first & SEG_WIDE) != 0;
     const uint8_t *tokp = sd.obs;
     const double *pp = a.params + (size_t)b * a.pstride;
     const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
     const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
     const int *cex = a.cex + (size_t)b * a.A;
 
-    const int tok0 = (int)tokp[0];
+    const int tok0 = seg_token(tokp, wide, 0);
     for (int k = tid; k < NP; k += THREADS) xs[0][k] = k < a.N ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
     if (tid < 3) smax[tid] = 0ull;
     __syncthreads();
@@ -447,8 +448,8 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
             }                                                                                       \
         }                                                                                           \
     } while (0)
-    int tok = len > 1 ? (int)tokp[1] : 0;
-    int tok_next = len > 2 ? (int)tokp[2] : tok;
+    int tok = len > 1 ? seg_token(tokp, wide, 1) : 0;
+    int tok_next = len > 2 ? seg_token(tokp, wide, 2) : tok;
     if constexpr (BigVec<NT>::PIPELINED) {
         const double *A = Ct + (size_t)tok * NP * NP;
 #pragma unroll
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) BV_LOAD(ps, An);
         }
-        const int tok_after = t + 2 < len ? (int)tokp[t + 2] : tok_next;
+        const int tok_after = t + 2 < len ? seg_token(tokp, wide, t + 2) : tok_next;
         const double *xc = &xs[cur][W * lm];   // x of step t-1 as stored (before its scale): the scale is applied to the dot products
         double mx = 0.0;
 #pragma unroll

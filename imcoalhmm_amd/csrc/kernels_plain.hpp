@@ -30,8 +30,15 @@ static constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 
 struct SegDesc {          // one segment of one chunk
     const uint8_t *obs;   // first column of the segment (16-byte aligned, padded past the end)
     uint32_t len;         // columns in this segment
-    uint32_t first;       // 1 = first segment of its chunk (single vector, starts from pi)
+    uint32_t first;       // bit 0: first segment of its chunk (single vector, starts from pi); bit 1: 16-bit tokens
 };
+static constexpr uint32_t SEG_FIRST = 1u, SEG_WIDE = 2u;
+
+// token t of a segment: bytes, or 16-bit ids on the wide dictionary levels (large-N kernels only)
+__device__ __forceinline__ int seg_token(const uint8_t *p, bool wide, int t)
+{
+    return wide ? (int)reinterpret_cast<const uint16_t *>(p)[t] : (int)p[t];
+}
 
 struct VecDesc {          // one propagated vector
     uint32_t seg;         // segment id
@@ -52,7 +59,7 @@ struct PropArgs {
     int *EX;               // [B][n_vecs_total]      power-of-two exponents
     // compressed path only
     int A;                 // alphabet of the token stream (raw symbols + merges)
-    const uint8_t *tok_left, *tok_right;   // [A] merge table (token z = left[z] then right[z])
+    const uint16_t *tok_left, *tok_right;  // [A] merge table (token z = left[z] then right[z])
 };
 
 static constexpr int WPB = 4;            // wavefronts per workgroup (256 threads)
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_propagate(PropArgs a)
     const VecDesc vd = a.vecs[min(vid, a.n_vecs - 1u)];
     const SegDesc sd = a.segs[vd.seg];
     const int len = (vid < a.n_vecs) ? (int)sd.len : 0;
-    const bool first = sd.first != 0;
+    const bool first = (sd.first & SEG_FIRST) != 0;
     const uint8_t *obs = sd.obs;
 
     double xo[R];

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(ZWAVES * 64) void k_zpropagate(PropArgs a)
     const VecDesc vd = a.vecs[min(vid, a.n_vecs - 1u)];
     const SegDesc sd = a.segs[vd.seg];
     const int len = valid ? (int)sd.len : 0;
-    const bool first = sd.first != 0;
+    const bool first = (sd.first & SEG_FIRST) != 0;
     const uint8_t *tokp = sd.obs;
 
     double xo[R];

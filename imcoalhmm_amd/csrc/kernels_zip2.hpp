@@ -187,7 +187,7 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate2(BigAr
     const uint32_t seg = blk.seg0 + (valid ? slot : 0);
     const SegDesc sd = a.segs[seg];
     const int len = valid ? (int)sd.len : 0;
-    const bool first = sd.first != 0;
+    const bool first = (sd.first & SEG_FIRST) != 0;
     const uint8_t *tokp = sd.obs;
 
     double P[RB][RB];

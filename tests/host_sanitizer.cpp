@@ -2,31 +2,45 @@
 #include "../imcoalhmm_amd/csrc/obs_io.hpp"
 #include <random>
 #include <cstdio>
+// Trains dictionaries (byte phase and, on the long low-entropy streams, the 16-bit round phase), encodes every
+// level, decodes it back, and round-trips the packed cache format.  Built with -fsanitize=address,undefined.
 int main() {
     std::mt19937 rng(1);
-    for (int rep = 0; rep < 20; ++rep) {
+    int wide_levels = 0;
+    for (int rep = 0; rep < 22; ++rep) {
         const int nsym = 2 + rep % 5;
-        const size_t L = (rep % 4 == 0) ? 3 : 5000 + 3777 * rep;
+        const bool big = rep >= 20;                       // two long streams that fill the byte dictionary
+        const size_t L = big ? 600000 : (rep % 4 == 0) ? 3 : 5000 + 3777 * rep;
         std::vector<uint8_t> obs(L);
-        for (auto &x : obs) x = (rng() % 10 < 8) ? 0 : rng() % nsym;
+        for (auto &x : obs) x = (rng() % 100 < (big ? 97 : 80)) ? 0 : rng() % nsym;
         imc::PairDict d;
         imc::train_dict(d, nsym, std::vector<uint8_t>(obs.begin() + 1, obs.end()), 4);
+        if (d.alphabet >= imc::kByteAlphabet) {
+            const std::vector<uint8_t> b = imc::encode_bytes(d, obs.data(), L, nullptr);
+            imc::train_dict_wide(d, std::vector<imc::tok_t>(b.begin() + 1, b.end()), 3);
+        }
+        if ((int)d.left.size() != d.alphabet || (int)d.right.size() != d.alphabet) { std::printf("dictionary size\n"); return 1; }
         imc::EncodedLevels enc;
         imc::encode_levels(d, obs.data(), L, enc);
         // decode each level and compare
         for (int l = 0; l < imc::kNumLevels; ++l) {
             std::vector<uint8_t> out;
-            std::vector<uint8_t> stack;
-            for (uint8_t t : enc.streams[l]) {
+            std::vector<int> stack;
+            if (enc.alphabet[l] > d.alphabet || enc.alphabet[l] < nsym) { std::printf("level alphabet\n"); return 1; }
+            if (enc.length[l] != (enc.is_wide[l] ? enc.wide[l].size() : enc.bytes[l].size())) { std::printf("level length\n"); return 1; }
+            if (l > 0 && enc.length[l] > enc.length[l - 1]) { std::printf("levels must not grow\n"); return 1; }
+            wide_levels += enc.is_wide[l];
+            for (size_t q = 0; q < enc.length[l]; ++q) {
+                const int t = enc.is_wide[l] ? (int)enc.wide[l][q] : (int)enc.bytes[l][q];
+                if (t >= enc.alphabet[l]) { std::printf("token out of alphabet\n"); return 1; }
                 stack.assign(1, t);
                 while (!stack.empty()) {
-                    uint8_t z = stack.back(); stack.pop_back();
-                    if (z < nsym) out.push_back(z);
+                    const int z = stack.back(); stack.pop_back();
+                    if (z < nsym) out.push_back((uint8_t)z);
                     else { stack.push_back(d.right[z]); stack.push_back(d.left[z]); }
                 }
             }
             if (out != obs) { std::printf("MISMATCH rep %d level %d\n", rep, l); return 1; }
-            for (uint8_t t : enc.streams[l]) if (t >= enc.alphabet[l]) { std::printf("token out of alphabet\n"); return 1; }
         }
         const char *path = "imc_sanitizer_tmp.imc";
         auto r = imc::write_cache(path, obs.data(), L, nsym);
@@ -34,6 +48,7 @@ int main() {
         auto r2 = imc::read_observation_file(path, nsym, back);
         if (r.code || r2.code || back != obs) { std::printf("cache mismatch\n"); return 1; }
     }
+    if (!wide_levels) { std::printf("the 16-bit dictionary phase never ran\n"); return 1; }
     std::printf("sanitizer run ok\n");
     return 0;
 }
