@@ -916,7 +916,8 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                 hipLaunchKernelGGL(kc->big_vec, dim3(grid), dim3(kc->big_vec_waves * 64), 0, stream, ba,
                                    (const BigBlock *)gr.d_big_blocks, (int)gr.big_blocks.size(), B);
                 note("k_big_vector<" + std::to_string(kc->G) + ">" + strm);
-                lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
+                if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A); }
+                else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }
                 HIP_TRY(hipGetLastError());
                 continue;
             }
@@ -928,7 +929,8 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             hipLaunchKernelGGL(kc->big_prop, dim3((unsigned)gr.big_blocks.size(), (unsigned)B), dim3(kc->G * 64), kc->big_lds,
                                stream, ba, (const BigBlock *)gr.d_big_blocks);
             note("k_big_propagate<" + std::to_string(kc->G) + ">" + strm);
-            lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
+            if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A); }
+            else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }
         } else if (gr.zip2) {
             BigArgs ba;
             ba.segs = p->d_segs; ba.seg_ids = nullptr; ba.seg_vec0 = nullptr; ba.blocks = gr.d_blocks;
@@ -945,7 +947,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             hipLaunchKernelGGL(kc->zip2, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64),
                                kc->zip2_lds(gr.A), stream, ba);
             note("k_zpropagate2<" + std::to_string(NP / 4) + ">" + strm);
-            if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A; }
+            if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A); }
             else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }
         } else if (gr.zip) {
             const size_t lds = kc->zip_lds(gr.A);
@@ -958,7 +960,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             dim3 grid((gr.n_vecs + vpb - 1) / vpb, (unsigned)B);
             hipLaunchKernelGGL(kc->zip, grid, dim3(ZWAVES * 64), lds, stream, a);
             note("k_zpropagate<" + std::to_string(kc->R) + "," + std::to_string(kc->G) + ">" + strm);
-            lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = (uint64_t)gr.A;
+            lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A);
         } else {
             const uint32_t vpb = (uint32_t)(WPB * kc->VPW);
             dim3 grid((gr.n_vecs + vpb - 1) / vpb, (unsigned)B);

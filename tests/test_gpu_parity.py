@@ -397,3 +397,42 @@ def test_matvec_chain_kernel_mid_n_many_chunks(oracle, n):
     assert np.max(np.abs(got / ref - 1)) < TOL
     for b, k in ((0, 0), (1, 39)):
         assert rel_err(got[b][k], oracle.forward_scaled(pis[b], Ts[b], Es[b], chunks[k])) < TOL
+
+
+@pytest.mark.parametrize("n", [28, 70])
+def test_wide_token_levels(oracle, n):
+    """Dictionaries beyond 256 tokens (16-bit streams) on the global-memory-table kernels: a 3e6-column first
+    chunk trains ~3500 tokens; GEMM chain (automatic and forced segmentation) and mat-vec chain kernels."""
+    set_zip(1)
+    pi, T, E = synth.random_hmm(n, 3, seed=5000 + n, stay=0.97)
+    chunks = [compressible(3_000_000, seed=5), compressible(50_000, seed=6), compressible(7, seed=7),
+              compressible(300_000, seed=8)]
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    ntok, alpha = fw[0].compressed_length(16384)
+    assert alpha > 1024 and ntok < 3_000_000 / 14
+    assert fw[1].compressed_length(16384)[1] == alpha           # later chunks share the dictionary
+    results = {}
+    # N <= 64: mode 3 pins the GEMM-chain kernels (a 7-column chunk keeps the automatic choice off them)
+    runs = (("auto", 1, 0), ("segmented", 1, 4096), ("matvec", 2, 0)) if n > 64 else (("gemm", 3, 0), ("segmented", 3, 4096))
+    for label, mode, seg in runs:
+        try:
+            set_zip(mode, reset=False)
+            set_seg(seg)
+            results[label] = forward_chunks_batch([f.handle for f in fw], pi[None], T[None], E[None], per_chunk=True)[0]
+            plan = _capi.last_plan()
+        finally:
+            set_seg(0)
+            set_zip(1, reset=False)
+        assert "k_big" in plan["kernels"], plan["kernels"]
+        assert plan["token_alphabet"] > 256, plan
+    for k in ((1, 2, 3) if n > 64 else (0, 1, 2, 3)):
+        want = oracle.forward_scaled(pi, T, E, chunks[k])
+        for label, got in results.items():
+            assert rel_err(got[k], want) < TOL, (n, label, k, got[k], want)
+    try:                                                        # the long chunk against the raw symbol stream
+        set_zip(0, reset=False)
+        raw = fw[0].forward(pi, T, E)
+    finally:
+        set_zip(1)
+    for label, got in results.items():
+        assert rel_err(got[0], raw) < TOL, (n, label)
