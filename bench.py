@@ -45,6 +45,9 @@ def main():
                     help="raw symbol stream (one step per alignment column), kernel chosen automatically")
     ap.add_argument("--mode", type=int, default=-1, help="imc_set_compression mode 0..5 (overrides --no-compress)")
     ap.add_argument("--cpu-sample-columns", type=int, default=0, help="cap on columns per CPU thread (0 = whole chunk)")
+    ap.add_argument("--split-file", action="store_true",
+                    help="N>1 only: ONE alignment of --columns (default 1e8) columns cut into contiguous slices, one per "
+                         "rank, stitched with exact transfer operators (strong scaling; dist.SplitAlignmentLikelihood)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses device 0 and the reduction runs "
                          "over gloo (RCCL refuses two ranks on one device); never used for reported numbers")
@@ -60,7 +63,7 @@ def main():
     import torch
     import torch.distributed as dist
     from imcoalhmm_amd import Forwarder, _capi, synth
-    from imcoalhmm_amd.dist import DistributedLikelihood, shard_indices
+    from imcoalhmm_amd.dist import DistributedLikelihood, SplitAlignmentLikelihood, shard_indices, slice_bounds
 
     dev_index = 0 if args.rehearse_on_one_gpu else local_rank
     torch.cuda.set_device(dev_index)
@@ -89,12 +92,20 @@ def main():
             "isolation-model" if key.startswith("iso") else "initial-migration-model", n_states, chunks_per_rank, cols,
             1 if key.startswith("iso") else 2)
         seeds = [20240001 + k for k in range(chunks_per_rank)]
+    elif args.split_file:
+        chunks_per_rank = 1
+        cols = args.columns or 100_000_000
+        workload = "%d states, ONE %d-column synthetic alignment cut into %d contiguous slices (BASELINE config[%d] across GPUs)" % (
+            n_states, cols, world, 1 if key.startswith("iso") else 2)
+        seeds = [20240001]
     else:
         chunks_per_rank = args.chunks or 32
         cols = args.columns or 10_000_000
         workload = "isolation-model %d states, %d x %d-column synthetic chunks sharded over %d GPUs (BASELINE config[3] slice)" % (
             n_states, chunks_per_rank * world, cols, world)
         seeds = [20240100 + i for i in shard_indices(chunks_per_rank * world, rank, world)]
+    split = world > 1 and args.split_file
+    lo, hi = slice_bounds(cols, rank, world) if split else (0, cols)
 
     t0 = time.time()
     forwarders = []
@@ -102,8 +113,11 @@ def main():
     for sd in seeds:
         # generated in 1e7-column pieces to bound host memory
         parts = [synth.sample_alignment(pi, T, E, min(10_000_000, cols - off), seed=sd * 1000 + k)
-                 for k, off in enumerate(range(0, cols, 10_000_000))]
+                 for k, off in enumerate(range(0, cols, 10_000_000)) if off < hi and off + 10_000_000 > lo]
         obs = parts[0] if len(parts) == 1 else np.concatenate(parts)
+        if split:            # this rank's contiguous slice of the one alignment
+            first_piece = (lo // 10_000_000) * 10_000_000
+            obs = obs[lo - first_piece:hi - first_piece]
         if first_chunk is None:
             first_chunk = obs
         forwarders.append(Forwarder.from_array(obs, 3))
@@ -117,7 +131,10 @@ def main():
         def build_hidden_markov_model(self, p):
             return pi, T, E
 
-    ll = DistributedLikelihood(FixedModel(), forwarders, device=dev, reduce_on_host=args.rehearse_on_one_gpu)
+    if split:
+        ll = SplitAlignmentLikelihood(FixedModel(), forwarders[0], gather_device=None if args.rehearse_on_one_gpu else dev)
+    else:
+        ll = DistributedLikelihood(FixedModel(), forwarders, device=dev, reduce_on_host=args.rehearse_on_one_gpu)
 
     model_build_ms = None
     if args.batch > 1:
@@ -215,7 +232,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if split else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

@@ -51,6 +51,9 @@ SIGNATURES = [
     ("imc_forward_batch_device", ctypes.c_int,
      [_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, ctypes.c_void_p,
       ctypes.c_void_p]),
+    ("imc_forward_state", ctypes.c_int,
+     [_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp,
+      ctypes.POINTER(ctypes.c_int)]),
     ("imc_set_segment_length", ctypes.c_int, [ctypes.c_size_t]),
     ("imc_set_compression", ctypes.c_int, [ctypes.c_int]),
     ("imc_dictionary_reset", ctypes.c_int, []),

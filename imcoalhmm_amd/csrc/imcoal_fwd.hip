@@ -460,13 +460,13 @@ static double matvec_step_cycles(double np2, int alphabet)
     return np2 / 3.0 * std::min(2.2, 1.0 + 0.03 * std::max(0.0, table_mb - 6.0));
 }
 
-int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, Plan **out)
+int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, bool op_mode, Plan **out)
 {
     std::vector<uint64_t> key;
     key.reserve(n_chunks + 5);
     for (int f = 0; f < n_chunks; ++f) key.push_back(chunks[f]->id);
     key.push_back((uint64_t)N); key.push_back((uint64_t)S); key.push_back((uint64_t)B);
-    key.push_back((uint64_t)g.seg_override); key.push_back((uint64_t)(g.compression * 4 + g.kernel_pref));
+    key.push_back((uint64_t)g.seg_override); key.push_back((uint64_t)(g.compression * 4 + g.kernel_pref + (op_mode ? 64 : 0)));
     for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
         if ((*it)->key == key) {
             g_plans.splice(g_plans.begin(), g_plans, it);
@@ -523,7 +523,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
                     for (int f : kv.second) lmax = std::max(lmax, (double)chunks[f]->ntok[l]);
                     const double np2 = (double)kc->NP * kc->NP;
                     const double c_vec = std::max(lmax * (np2 / 8.0 + 1500.0), toks * B / (double)g.cus * matvec_step_cycles(np2, o0->alphabet[l]));
-                    if (g.kernel_pref == 1 || (g.kernel_pref == 0 && c_vec < c_main)) c_main = c_vec;
+                    if (!op_mode && (g.kernel_pref == 1 || (g.kernel_pref == 0 && c_vec < c_main))) c_main = c_vec;
                 } else {     // ~5200 cycles per row-step at N=20; every workgroup rebuilds the table
                     c_tab = (o0->alphabet[l] - S) * (400.0 + n3 / 64.0);
                     c_main = std::max(16.0, toks * B / ((double)g.cus * 32.0)) * 0.65 * n3;
@@ -587,7 +587,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             if (std::getenv("IMC_DEBUG"))
                 std::fprintf(stderr, "[imc] plan: GEMM chain seg %zu cost %.3g cycles; mat-vec chain cost %.3g cycles\n",
                              gr.seglen, cost_gemm, cost_vec);
-            if (g.kernel_pref == 1 || (g.kernel_pref == 0 && cost_vec < cost_gemm)) {
+            if (!op_mode && (g.kernel_pref == 1 || (g.kernel_pref == 0 && cost_vec < cost_gemm))) {
                 gr.bigvec = true;
                 gr.seglen = std::max<size_t>(16, round_up(lmax, 16));
             }
@@ -638,7 +638,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         }
         if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);   // tests: force stitching
         if (gr.bigvec)
-            for (size_t L : lens) gr.bigvec = gr.bigvec && L <= gr.seglen;
+            for (size_t L : lens) gr.bigvec = gr.bigvec && L <= gr.seglen && !op_mode;
     }
     // ---- segments in chunk order ----
     std::vector<SegDesc> segs;
@@ -654,9 +654,10 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         const size_t sl = round_up((L + K0 - 1) / K0, 16);   // equalised, multiple of 16
         for (size_t off = 0, k = 0; off < L; off += sl, ++k) {
             const bool wide = gr.zip && chunks[f]->wide[gr.level];
+            const bool fst = k == 0 && !op_mode;   // operator mode: the chunk's own first segment is an operator too
             segs.push_back(SegDesc{base + off * (wide ? 2 : 1), (uint32_t)std::min(sl, L - off),
-                                   (k == 0 ? SEG_FIRST : 0u) | (wide ? SEG_WIDE : 0u)});
-            seg_first.push_back(k == 0);
+                                   (fst ? SEG_FIRST : 0u) | (wide ? SEG_WIDE : 0u)});
+            seg_first.push_back(fst);
         }
     }
     chunk_seg[n_chunks] = (uint32_t)segs.size();
@@ -722,7 +723,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
             const uint32_t s0 = cur.chunk_seg[f], s1 = cur.chunk_seg[f + 1];
             for (uint32_t rb = s0; rb < s1; rb += gsz) {
                 const uint32_t re = std::min(rb + gsz, s1);
-                const bool fst = rb == s0;
+                const bool fst = rb == s0 && !op_mode;
                 nx.vec0.push_back(nx.n_vecs);
                 nx.first.push_back(fst);
                 const int nvv = fst ? 1 : N;
@@ -1011,7 +1012,7 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
     if (int rc = check_args(chunks, n_chunks, B, N, S, pis, Ts, Es)) return rc;
     HIP_TRY(hipSetDevice(g.device));
     Plan *p = nullptr;
-    if (int rc = build_plan(chunks, n_chunks, N, S, B, &p)) return rc;
+    if (int rc = build_plan(chunks, n_chunks, N, S, B, false, &p)) return rc;
     stage_params(p, pis, Ts, Es);
     // First call of a plan runs eagerly (kernel attributes get set); the second is captured into a hipGraph that
     // every later call replays: one graph launch instead of ~8 stream operations per evaluation.
@@ -1042,6 +1043,46 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
         }
         if (out_sum) out_sum[b] = tot;
     }
+    return IMC_OK;
+}
+
+// State export (imc_forward_state): the plan runs as usual, then every chunk's final vector (from pi) or transfer
+// operator is copied out with its power-of-two exponents instead of being reduced to a log-likelihood.
+int run_state(const imc_obs *const *chunks, int n_chunks, bool op_mode, int B, int N, int S, const double *pis,
+              const double *Ts, const double *Es, double *out_state, int *out_exp)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (int rc = ensure_ctx()) return rc;
+    if (int rc = check_args(chunks, n_chunks, B, N, S, pis, Ts, Es)) return rc;
+    if (!out_state || !out_exp) return fail(IMC_ERR_ARG, "output buffer is null");
+    for (int f = 0; f < n_chunks; ++f)
+        if (chunks[f]->L == 0) return fail(IMC_ERR_ARG, "imc_forward_state: empty chunk");
+    HIP_TRY(hipSetDevice(g.device));
+    Plan *p = nullptr;
+    if (int rc = build_plan(chunks, n_chunks, N, S, B, op_mode, &p)) return rc;
+    stage_params(p, pis, Ts, Es);
+    if (int rc = enqueue(p, g.stream, p->h_out_dev)) return rc;
+    ++p->calls;
+    for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
+    g.last_kernels = p->kernels;
+    const size_t per = op_mode ? (size_t)N * N : (size_t)N, pere = op_mode ? (size_t)N : 1;
+    const size_t n_state = (size_t)B * n_chunks * per, n_exp = (size_t)B * n_chunks * pere;
+    double *d_state = nullptr;
+    int *d_exp = nullptr;
+    hipError_t e = hipMalloc((void **)&d_state, std::max<size_t>(n_state * 8, 16));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_exp, std::max<size_t>(n_exp * 4, 16));
+    if (e == hipSuccess) {
+        const Level &last = p->levels.back();
+        hipLaunchKernelGGL(k_export, dim3((unsigned)n_chunks, (unsigned)B), dim3(256), 0, g.stream, p->d_final_vec, n_chunks, N,
+                           p->kc->NP, last.n_vecs, last.d_P, last.d_EX, op_mode ? 1 : 0, d_state, d_exp);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_state, d_state, n_state * 8, hipMemcpyDeviceToHost, g.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_exp, d_exp, n_exp * 4, hipMemcpyDeviceToHost, g.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
+    (void)hipFree(d_state);
+    (void)hipFree(d_exp);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP, std::string("state export: ") + hipGetErrorString(e));
     return IMC_OK;
 }
 
@@ -1179,6 +1220,12 @@ int imc_obs_free(imc_obs *obs)
     return IMC_OK;
 }
 
+int imc_forward_state(const imc_obs *const *chunks, int n_chunks, int as_operator, int B, int N, int S, const double *pis,
+                      const double *Ts, const double *Es, double *out_state, int *out_exp)
+{
+    return run_state(chunks, n_chunks, as_operator != 0, B, N, S, pis, Ts, Es, out_state, out_exp);
+}
+
 int imc_forward(const imc_obs *const *chunks, int n_chunks, int N, int S, const double *pi, const double *T,
                 const double *E, double *out_loglik)
 {
@@ -1210,7 +1257,7 @@ int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, 
     HIP_TRY(hipSetDevice(g.device));
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g.stream;
     Plan *p = nullptr;
-    if (int rc = build_plan(chunks, n_chunks, N, S, B, &p)) return rc;
+    if (int rc = build_plan(chunks, n_chunks, N, S, B, false, &p)) return rc;
     // the pinned staging buffer is reused by the next call: wait for the previous upload first
     HIP_TRY(hipStreamSynchronize(st));
     stage_params(p, pis, Ts, Es);

@@ -184,6 +184,31 @@ __global__ void k_finish(const int32_t *final_vec, int n_chunks, int N, int NP, 
     out[(size_t)b * n_chunks + f] = r;
 }
 
+// State export: chunk f's single remaining unit, unreduced.  op == 0: its vector a[i] (N doubles, one exponent);
+// op == 1: its transfer operator P[i][c] (N x N row-major, one exponent per column c).  Value = stored * 2^exponent.
+__global__ void k_export(const int32_t *final_vec, int n_chunks, int N, int NP, uint32_t n_vecs, const double *P,
+                         const int *EX, int op, double *out_state, int *out_exp)
+{
+    const int f = blockIdx.x, b = blockIdx.y;
+    const int32_t v = final_vec[f];
+    if (v < 0) return;
+    const double *src = P + ((size_t)b * n_vecs + v) * NP;
+    const int *ex = EX + (size_t)b * n_vecs + v;
+    if (op) {
+        double *dst = out_state + ((size_t)b * n_chunks + f) * N * N;
+        int *de = out_exp + ((size_t)b * n_chunks + f) * N;
+        for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
+            const int i = idx / N, c = idx - i * N;
+            dst[idx] = src[(size_t)i * NP + c];
+        }
+        for (int c = threadIdx.x; c < N; c += blockDim.x) de[c] = ex[c];
+    } else {
+        double *dst = out_state + ((size_t)b * n_chunks + f) * N;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) dst[i] = src[i];
+        if (threadIdx.x == 0) out_exp[(size_t)b * n_chunks + f] = ex[0];
+    }
+}
+
 // partial[b] = sum_f per_chunk[b][f], left to right from 0.0 (likelihood.py:33)
 __global__ void k_sum_chunks(const double *per_chunk, int n_chunks, int B, double *partial)
 {

@@ -80,3 +80,72 @@ class DistributedLikelihood(object):
         if valid:
             out[valid] = self.forward_params_batch(*build_hmms(self.model, [thetas[k] for k in valid]))
         return out
+
+
+def slice_bounds(n_columns, rank, world_size):
+    """Contiguous column range [begin, end) of rank's slice of one long alignment (balanced to one column)."""
+    return (n_columns * rank) // world_size, (n_columns * (rank + 1)) // world_size
+
+
+class SplitAlignmentLikelihood(object):
+    """ONE long alignment across GPUs: rank r holds columns ``slice_bounds(L, r, world)``
+    as its own Forwarder; rank 0 exports the forward vector after its slice, every other rank its slice's exact
+    N x N transfer operator (``imc_forward_state``); one ``all_gather`` of N*N + N doubles per parameter set and
+    a tiny ordered combine give every rank the log-likelihood of the whole alignment.
+
+    ``local_state(pis, Ts, Es, as_operator) -> (values, exponents)`` may be injected (CPU/gloo tests).
+    """
+
+    def __init__(self, model, local_forwarder, group=None, local_state=None, gather_device=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.model = model
+        self.forwarder = local_forwarder
+        self.group = group
+        self.gather_device = gather_device       # None: host tensors (gloo); a cuda device for RCCL
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._local_state = local_state or self._hip_state
+
+    def _hip_state(self, pis, Ts, Es, as_operator):
+        values, exps = hmm.forward_states([self.forwarder.handle], pis, Ts, Es, as_operator)
+        return values[:, 0], exps[:, 0]
+
+    def forward_params_batch(self, pis, Ts, Es):
+        torch = self._torch
+        pis, Ts, Es = hmm._batch_params(pis, Ts, Es)
+        B, n = pis.shape
+        values, exps = self._local_state(pis, Ts, Es, self.rank > 0)
+        # one fixed-size record per rank: N*N values (the vector sits in the first N) + N exponents
+        rec = np.zeros((B, n * n + n), dtype=np.float64)
+        if self.rank > 0:
+            rec[:, :n * n] = np.asarray(values, dtype=np.float64).reshape(B, n * n)
+            rec[:, n * n:] = np.asarray(exps, dtype=np.float64).reshape(B, n)
+        else:
+            rec[:, :n] = np.asarray(values, dtype=np.float64).reshape(B, n)
+            rec[:, n * n] = np.asarray(exps, dtype=np.float64).reshape(B)
+        mine = torch.from_numpy(rec)
+        if self.gather_device is not None:
+            mine = mine.to(self.gather_device)
+        if self.world_size > 1:
+            parts = [torch.empty_like(mine) for _ in range(self.world_size)]
+            self._dist.all_gather(parts, mine, group=self.group)
+        else:
+            parts = [mine]
+        parts = [p.cpu().numpy() for p in parts]
+        out = np.empty(B, dtype=np.float64)
+        for b in range(B):
+            ops = [parts[r][b, :n * n].reshape(n, n) for r in range(1, self.world_size)]
+            opx = [parts[r][b, n * n:].astype(np.int64) for r in range(1, self.world_size)]
+            out[b] = hmm.combine_states(parts[0][b, :n], int(parts[0][b, n * n]), ops, opx)
+        return out
+
+    def forward_params(self, pi, T, E):
+        pi, T, E = hmm._params(pi, T, E)
+        return float(self.forward_params_batch(pi[None], T[None], E[None])[0])
+
+    def __call__(self, *parameters):
+        if not self.model.valid_parameters(*parameters):
+            return -float('inf')
+        return self.forward_params(*self.model.build_hidden_markov_model(*parameters))

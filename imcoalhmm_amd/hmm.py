@@ -62,6 +62,43 @@ def forward_chunks_batch(handles, pis, Ts, Es, per_chunk=False):
     return out
 
 
+def forward_states(handles, pis, Ts, Es, as_operator):
+    """State of every chunk instead of its log-likelihood (``imc_forward_state``).
+
+    ``as_operator=False``: forward vectors started from pi -> ``(values[B, n, N], exponents[B, n])``;
+    ``as_operator=True``: exact transfer operators -> ``(values[B, n, N, N], exponents[B, n, N])`` with one
+    exponent per column.  True value = ``values * 2**exponents``.
+    """
+    pis, Ts, Es = _batch_params(pis, Ts, Es)
+    B, n = pis.shape
+    k = len(handles)
+    state = np.zeros((B, k, n, n) if as_operator else (B, k, n), dtype=np.float64)
+    exps = np.zeros((B, k, n) if as_operator else (B, k), dtype=np.int32)
+    _capi.check(_capi.lib().imc_forward_state(
+        _capi.handle_array(handles), k, 1 if as_operator else 0, B, n, Es.shape[2], _capi.dptr(pis),
+        _capi.dptr(Ts), _capi.dptr(Es), _capi.dptr(state), exps.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+    return state, exps
+
+
+def combine_states(vector, vector_exp, operators, operator_exps):
+    """log sum_i (P_k ... P_1 a)_i for one parameter set: ``vector`` a (N,) with scalar exponent, then the
+    operators ``(k, N, N)`` with per-column exponents ``(k, N)`` in slice order.  Exact power-of-two rescaling."""
+    a = np.asarray(vector, dtype=np.float64)
+    e = int(vector_exp)
+    for P, pe in zip(operators, operator_exps):
+        pe = np.asarray(pe, dtype=np.int64)
+        top = int(pe.max())
+        a = np.asarray(P, dtype=np.float64) @ np.ldexp(a, (pe - top).astype(np.int32))
+        e += top
+        m = a.max()
+        if m > 0 and np.isfinite(m):
+            shift = int(np.frexp(m)[1])
+            a = np.ldexp(a, -shift)
+            e += shift
+    total = a.sum()
+    return float(np.log(total) + e * np.log(2.0)) if total > 0 else (float('-inf') if total == 0 else float('nan'))
+
+
 class Forwarder(object):
     """``Forwarder(input_filename, NSYM)`` - same surface as the reference class (hmm.py:10-21).
 

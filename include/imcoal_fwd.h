@@ -104,6 +104,19 @@ int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, 
                              const double *pis, const double *Ts, const double *Es,
                              double *d_out_partial, void *hip_stream);
 
+/* One long alignment split over GPUs ("a single long file across GPUs"): every rank holds a
+ * contiguous slice as its own chunk and exports the slice's STATE instead of a log-likelihood.
+ *   as_operator == 0: the forward vector after the chunk, started from pi (the first slice):
+ *       out_state[B][n_chunks][N], out_exp[B][n_chunks];         a_i = out_state * 2^out_exp
+ *   as_operator != 0: the chunk's exact transfer operator, every column of the chunk (the first included)
+ *       acting as C_o = diag(E[:,o]) T':   out_state[B][n_chunks][N][N] row-major P[i][c], out_exp[B][n_chunks][N]
+ *       (one exponent per column c);                              P_ic = out_state * 2^out_exp[c]
+ * The caller gathers the ranks' states (N^2 + N numbers each) and applies them in order; the log-likelihood of
+ * the whole alignment is log sum_i (P_last ... P_1 a)_i.  There is no counterpart in the reference (its
+ * Likelihood only sums independent files, likelihood.py:33); empty chunks are refused. */
+int imc_forward_state(const imc_obs *const *chunks, int n_chunks, int as_operator, int B, int N, int S,
+                      const double *pis, const double *Ts, const double *Es, double *out_state, int *out_exp);
+
 /* Tuning / measurement ------------------------------------------------------------------ */
 /* Target segment length, in stream elements (columns, or tokens on the compressed path), for the
  * parallel-in-time split (0 = automatic). */
@@ -113,8 +126,9 @@ int imc_set_segment_length(size_t columns);
  *      operator table fits LDS for the model's N; the kernel variant is chosen from the segment/chunk ratio.
  *   0: raw symbol stream only (also skips the compression of chunks created while it is 0); kernel chosen
  *      automatically.
- *   2 / 3: as 1 but pin the kernel: 2 = one vector per lane group (k_zpropagate), 3 = register-blocked
- *      operator per 16-lane row (k_zpropagate2, N <= 24).
+ *   2 / 3: as 1 but pin the kernel: 2 = one vector per lane group (k_zpropagate; N > 64: the mat-vec chain kernel
+ *      k_big_vector, one segment per chunk), 3 = register-blocked operator per 16-lane row (k_zpropagate2, N <= 24;
+ *      24 < N: the MFMA GEMM-chain kernels).
  *   4 / 5: as 0 but pin the kernel: 4 = k_propagate (T' in registers, LDS broadcast), 5 = k_zpropagate2. */
 int imc_set_compression(int mode);
 /* Forget the per-process pair dictionaries: the next sufficiently long chunk trains a new one.

@@ -89,3 +89,86 @@ def test_shard_indices_cover_and_balance():
             parts = [shard_indices(n, r, w) for r in range(w)]
             assert sorted(sum(parts, [])) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _numpy_state(pi, T, E, obs, as_operator):
+    """Reference slice state with plain numpy: scaled vector from pi, or scaled transfer operator."""
+    n = pi.shape[0]
+    if as_operator:
+        P = np.eye(n)
+        exps = np.zeros(n, dtype=np.int64)
+        for o in obs:
+            P = (E[:, o][:, None] * T.T) @ P
+            m = P.max(axis=0)
+            sh = np.frexp(m)[1]
+            P = np.ldexp(P, -sh[None, :])
+            exps += sh
+        return P, exps
+    a = pi * E[:, obs[0]]
+    e = 0
+    for o in obs[1:]:
+        a = E[:, o] * (T.T @ a)
+        sh = int(np.frexp(a.max())[1])
+        a = np.ldexp(a, -sh)
+        e += sh
+    return a, e
+
+
+def _split_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from imcoalhmm_amd import synth
+    from imcoalhmm_amd.dist import SplitAlignmentLikelihood, slice_bounds
+    from oracle import oracle_lib
+    d = np.load(os.path.join(REPO, "tests", "golden", "hmm_params.npz"))
+    hm = [(d["iso10_t%d_pi" % k], d["iso10_t%d_T" % k], d["iso10_t%d_E" % k]) for k in (0, 1)]
+    whole = synth.sample_alignment(*hm[0], 6001, seed=77)
+    lo, hi = slice_bounds(whole.size, rank, world)
+    mine = whole[lo:hi]
+
+    def local_state(pis, Ts, Es, as_operator):
+        vals, exps = zip(*[_numpy_state(pis[b], Ts[b], Es[b], mine, as_operator) for b in range(pis.shape[0])])
+        return np.stack(vals), np.stack([np.asarray(x) for x in exps])
+
+    class M(object):
+        def valid_parameters(self, p):
+            return all(p > 0)
+
+        def build_hidden_markov_model(self, p):
+            return hm[0] if p[0] < 2 else hm[1]
+
+    ll = SplitAlignmentLikelihood(M(), object(), local_state=local_state)
+    got = [ll(np.array([1.0])), ll(np.array([3.0])), ll(np.array([-1.0]))]
+    pis, Ts, Es = (np.stack([h[k] for h in hm]) for k in range(3))
+    batch = ll.forward_params_batch(pis, Ts, Es)
+    want = [oracle_lib.forward_scaled(*h, whole) for h in hm]
+    q.put((rank, (lo, hi), got, batch.tolist(), want))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_alignment_world(world):
+    """One alignment cut into contiguous slices, one per rank: vector from rank 0, operators from the others,
+    all_gather + ordered combine (dist.SplitAlignmentLikelihood) equals the single-chain forward."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bounds = sorted(r[1] for r in res)
+    assert bounds[0][0] == 0 and bounds[-1][1] == 6001
+    assert all(a[1] == b[0] for a, b in zip(bounds[:-1], bounds[1:]))       # contiguous, no overlap
+    for rank, _, got, batch, want in res:
+        assert abs(got[0] - want[0]) / abs(want[0]) < 1e-12
+        assert abs(got[1] - want[1]) / abs(want[1]) < 1e-12
+        assert got[2] == -float("inf")
+        assert abs(batch[0] - want[0]) / abs(want[0]) < 1e-12 and abs(batch[1] - want[1]) / abs(want[1]) < 1e-12
+    assert all(r[2][:2] == res[0][2][:2] for r in res)                     # identical on all ranks

@@ -436,3 +436,45 @@ def test_wide_token_levels(oracle, n):
         set_zip(1)
     for label, got in results.items():
         assert rel_err(got[0], raw) < TOL, (n, label)
+
+
+@pytest.mark.parametrize("n,mode", [(3, 1), (10, 0), (20, 1), (20, 2), (28, 3), (40, 1), (70, 1), (150, 1)])
+def test_state_export_split_alignment(oracle, n, mode):
+    """imc_forward_state: one alignment cut into contiguous slices (as `dist.SplitAlignmentLikelihood` does
+    across GPUs) - vector from the first slice, exact transfer operators from the others - recombines to the
+    log-likelihood of the whole alignment."""
+    from imcoalhmm_amd.hmm import combine_states, forward_states
+    set_zip(mode)
+    hmms = [synth.random_hmm(n, 3, seed=8100 + 3 * n + b, stay=0.95) for b in range(2)]
+    pis, Ts, Es = (np.stack([h[k] for h in hmms]) for k in range(3))
+    whole = compressible(90_000 if n <= 70 else 30_000, seed=n + 1)
+    cuts = [0, 40_000, 40_001, 41_000, whole.size] if n <= 70 else [0, 12_000, 12_001, whole.size]
+    pieces = [whole[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    fw = [Forwarder.from_array(p, 3) for p in pieces]
+    fw_whole = Forwarder.from_array(whole, 3)
+    for seg in (0, 256):
+        try:
+            set_seg(seg)
+            vec, vexp = forward_states([fw[0].handle], pis, Ts, Es, as_operator=False)
+            ops, oexp = forward_states([f.handle for f in fw[1:]], pis, Ts, Es, as_operator=True)
+            want_gpu = forward_chunks_batch([fw_whole.handle], pis, Ts, Es)
+        finally:
+            set_seg(0)
+        assert vec.shape == (2, 1, n) and ops.shape == (2, len(fw) - 1, n, n) and oexp.shape == (2, len(fw) - 1, n)
+        for b in range(2):
+            got = combine_states(vec[b, 0], vexp[b, 0], ops[b], oexp[b])
+            want = oracle.forward_scaled(pis[b], Ts[b], Es[b], whole)
+            assert rel_err(got, want) < TOL, (n, mode, seg, b, got, want)
+            assert rel_err(want_gpu[b], want) < TOL
+            # the exported vector alone reproduces the first slice's own log-likelihood
+            first = combine_states(vec[b, 0], vexp[b, 0], [], [])
+            assert rel_err(first, oracle.forward_scaled(pis[b], Ts[b], Es[b], pieces[0])) < TOL
+    # a one-column operator is diag(E[:,o]) T'
+    P, pe = forward_states([fw[1].handle], pis[:1], Ts[:1], Es[:1], as_operator=True)
+    assert pieces[1].size == 1
+    o = int(pieces[1][0])
+    assert np.allclose(np.ldexp(P[0, 0], pe[0, 0][None, :]), Es[0][:, o][:, None] * Ts[0].T, rtol=1e-13, atol=0)
+    empty = Forwarder.from_array(np.zeros(0, dtype=np.uint8), 3)
+    with pytest.raises(ValueError):
+        forward_states([empty.handle], pis, Ts, Es, True)
+    set_zip(1)
