@@ -316,9 +316,9 @@ KernelChoice kChoices[] = {
     make_kc<4, 1, 2>(), make_kc<4, 2, 2>(), make_kc<4, 3, 2>(), make_kc<4, 4, 2>(), make_kc<4, 5, 2>(),
     make_kc<3, 8, 2>(), make_kc<2, 14, 2>(), make_kc<2, 16, 2>(), make_kc<2, 20, 1>(), make_kc<1, 48, 1>(),
     make_kc<1, 56, 1>(), make_kc<1, 64, 1>(),
-    make_big<6, 1>(), make_big<8, 2>(), make_big<10, 2>(), make_big<12, 3>(),
+    make_big<6, 1>(), make_big<8, 2>(), make_big<10, 2>(), make_big<12, 3>(), make_big<14, 7>(), make_big<16, 8>(),
 };
-constexpr int IMC_MAX_N = 192;
+constexpr int IMC_MAX_N = 256;
 
 // MFMA GEMM-chain variants for 24 < N <= 64 (small workgroups, several per CU): used instead of the vector
 // kernels when a launch is dominated by operator segments (long chunks).

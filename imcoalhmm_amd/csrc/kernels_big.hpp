@@ -55,12 +55,12 @@ struct BigLds {
     static constexpr size_t bytes = (size_t)2 * (A_DOUBLES + B_DOUBLES) * 8;
 };
 
-template <int NT>
+template <int NT, int TC = NT>
 __device__ __forceinline__ void big_gemm(const double *__restrict__ A, const double *__restrict__ B, int row0, int col0,
-                                         int tid, double *lds, v4f64 (&acc)[1][NT])
+                                         int tid, double *lds, v4f64 (&acc)[1][TC])
 {
     using L = BigLds<NT>;
-    constexpr int NP = 16 * NT, TR = 1, TC = NT, THREADS = NT * 64;   // wavefront w computes tile-row w
+    constexpr int NP = 16 * NT, TR = 1, THREADS = NT * 64;   // wavefront w computes tile-row w, TC tile-columns from col0
     constexpr int APS = L::APS, BPS = L::BPS;
     const int lane = tid & 63, lm = lane & 15, lg = lane >> 4;
     // staging assignment: two double2 of the A panel (NP rows x 8 double2) and two of the B panel
@@ -127,6 +127,25 @@ __device__ __forceinline__ void big_gemm(const double *__restrict__ A, const dou
 
 // Workgroup-wide maximum of the (non-negative) accumulator entries -> exponent e with max in [2^(e-1), 2^e).
 // smax: two LDS slots used alternately (slot `which`); the other slot is cleared for the next call.
+template <int TC>
+__device__ __forceinline__ double big_tile_max(const v4f64 (&acc)[1][TC])
+{
+    double mx = 0.0;
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double v = acc[0][tc][q];
+            mx = (v > mx || v != v) ? v : mx;
+        }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double o = __shfl_xor(mx, m, 64);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    return mx;
+}
+
 template <int NT>
 __device__ __forceinline__ int big_exponent(const v4f64 (&acc)[1][NT], unsigned long long *smax, int which, int tid)
 {
@@ -156,11 +175,11 @@ __device__ __forceinline__ int big_exponent(const v4f64 (&acc)[1][NT], unsigned 
 }
 
 // Store the scaled accumulator tiles: D layout of v_mfma_f64_16x16x4_f64 is row = (lane>>4) + 4*reg, col = lane&15.
-template <int NT>
-__device__ __forceinline__ void big_store(double *__restrict__ D, int row0, int col0, int lane, const v4f64 (&acc)[1][NT],
+template <int TC>
+__device__ __forceinline__ void big_store(double *__restrict__ D, int row0, int col0, int lane, const v4f64 (&acc)[1][TC],
                                           int e, int row_limit, int col_limit, size_t ld)
 {
-    constexpr int TR = 1, TC = NT;
+    constexpr int TR = 1;
     const int lm = lane & 15, lg = lane >> 4;
 #pragma unroll
     for (int tr = 0; tr < TR; ++tr)
@@ -208,11 +227,42 @@ __global__ __launch_bounds__(NT * 64) void k_big_table_level(BigArgs a, const ui
     __syncthreads();
     const int row0 = wave * 16, col0 = 0;
     const int zl = a.tok_left[z], zr = a.tok_right[z];
-    v4f64 acc[1][NT];
-    big_gemm<NT>(Ct + (size_t)zr * NP * NP, Ct + (size_t)zl * NP * NP, row0, col0, tid, panels, acc);
-    const int e = big_exponent<NT>(acc, smax, 0, tid);
-    big_store<NT>(Ct + (size_t)z * NP * NP, row0, col0, lane, acc, e, NP, NP, NP);
-    if (tid == 0) cex[z] = cex[zl] + cex[zr] + e;
+    if constexpr (NT <= 12) {
+        v4f64 acc[1][NT];
+        big_gemm<NT>(Ct + (size_t)zr * NP * NP, Ct + (size_t)zl * NP * NP, row0, col0, tid, panels, acc);
+        const int e = big_exponent<NT>(acc, smax, 0, tid);
+        big_store<NT>(Ct + (size_t)z * NP * NP, row0, col0, lane, acc, e, NP, NP, NP);
+        if (tid == 0) cex[z] = cex[zl] + cex[zr] + e;
+    } else {
+        // 14-16 wavefronts leave 128 registers per lane: the product is formed in two column halves, stored
+        // unscaled, and rescaled in place once the maximum over both halves is known (every lane rewrites
+        // exactly the elements it stored)
+        constexpr int HALF = NT / 2;
+        static_assert(NT % 2 == 0, "column halves");
+        double *D = Ct + (size_t)z * NP * NP;
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+            v4f64 acc[1][HALF];
+            big_gemm<NT, HALF>(Ct + (size_t)zr * NP * NP, Ct + (size_t)zl * NP * NP, row0, h * HALF * 16, tid, panels, acc);
+            const double mx = big_tile_max<HALF>(acc);
+            if (lane == 0) atomicMax(&smax[0], (unsigned long long)__double_as_longlong(mx));
+            big_store<HALF>(D, row0, h * HALF * 16, lane, acc, 0, NP, NP, NP);
+            __syncthreads();   // the LDS panels are reused by the next half
+        }
+        const double m = __longlong_as_double((long long)smax[0]);
+        int e = 0;
+        (void)frexp(m, &e);
+        e = (m > 0.0 && m < INFINITY) ? e : 0;
+        const int lm = lane & 15, lg = lane >> 4;
+#pragma unroll 1
+        for (int tc = 0; tc < NT; ++tc)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double *p = D + (size_t)(row0 + lg + 4 * q) * NP + tc * 16 + lm;
+                *p = ldexp(*p, -e);
+            }
+        if (tid == 0) cex[z] = cex[zl] + cex[zr] + e;
+    }
 }
 
 // One workgroup per (segment, column slab, parameter set): P[:, slab] <- C_tok * P[:, slab] over the segment's
@@ -391,7 +441,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
 template <int NT>
 struct BigVec {
     // every pass covers 4 WAVES rows and the passes tile NP = 16 NT rows exactly; <= 48 operator doubles per lane
-    static constexpr int WAVES = NT == 3 ? 12 : 8;
+    static constexpr int WAVES = NT == 3 ? 12 : NT == 14 ? 14 : NT > 12 ? 16 : 8;
     static constexpr bool PIPELINED = NT <= 10;      // beyond that the double set of operator registers would spill
 };
 
@@ -457,16 +507,13 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     }
     for (int t = 1; t < len; ++t) {
         const double *An = Ct + (size_t)(BigVec<NT>::PIPELINED ? tok_next : tok) * NP * NP;
-        if constexpr (!BigVec<NT>::PIPELINED) {
-#pragma unroll
-            for (int ps = 0; ps < PASSES; ++ps) BV_LOAD(ps, An);
-        }
         const int tok_after = t + 2 < len ? seg_token(tokp, wide, t + 2) : tok_next;
         const double *xc = &xs[cur][W * lm];   // x of step t-1 as stored (before its scale): the scale is applied to the dot products
         double mx = 0.0;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = ps * ROWS_PER_PASS + wave * 4 + lg;
+            if constexpr (!BigVec<NT>::PIPELINED) BV_LOAD(ps, An);   // (the compiler overlaps passes as far as registers allow)
             double p = 0.0;
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {

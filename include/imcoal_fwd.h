@@ -13,7 +13,7 @@
  *   Every chunk (alignment file) restarts from pi and chunk log-likelihoods are summed
  *   left-to-right starting from 0.0 (likelihood.py:33).
  *   A zero-probability sequence yields -inf (not an error); NaN in -> NaN out.
- *   Limits: N <= 192 states, S <= 256 symbols, < 2^31 columns per chunk, and |log-likelihood| of one chunk
+ *   Limits: N <= 256 states, S <= 256 symbols, < 2^31 columns per chunk, and |log-likelihood| of one chunk
  *   below ~1.4e9 nats (the power-of-two exponents of a chunk are summed in int32).
  *
  * Ownership: input buffers are borrowed for the duration of the call only.  Observations are

@@ -24,7 +24,7 @@ def _chunk(rng, nsym, L):
 def test_random_dispatch(oracle, case):
     rng = np.random.default_rng(1000 + case)
     L = _capi.lib()
-    n = int(rng.choice([1, 2, 3, 5, 8, 10, 13, 16, 20, 22, 24, 27, 32, 40, 47, 64, 65, 90, 128, 150, 192]))
+    n = int(rng.choice([1, 2, 3, 5, 8, 10, 13, 16, 20, 22, 24, 27, 32, 40, 47, 64, 65, 90, 128, 150, 192, 200, 256]))
     nsym = int(rng.choice([2, 3, 3, 3, 4, 7]))
     mode = int(rng.integers(0, 6))
     seg = int(rng.choice([0, 0, 16, 48, 256, 1000]))

@@ -78,7 +78,7 @@ def test_segmentation_invariance(hmm_params, example_pairs, golden_loglik, seg, 
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 10, 12, 13, 16, 17, 20, 21, 24, 25, 28, 29, 32, 33, 40, 41, 48, 50, 56, 57, 64,
-                               65, 96, 97, 128, 150, 160, 161, 192])
+                               65, 96, 97, 128, 150, 160, 161, 192, 200, 225, 256])
 @pytest.mark.parametrize("nsym", [3])
 def test_random_hmms_all_kernel_shapes(oracle, n, nsym):
     """Every (R,G) instantiation, padded and unpadded N, with stitching forced (seg=160)."""
@@ -184,7 +184,7 @@ def test_text_file_constructor(oracle, hmm_params, example_pairs, tmp_path):
     assert len(g) == obs.size and g.forward(pi, T, E) == f.forward(pi, T, E)
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, 8, 10, 12, 16, 20, 23, 24, 28, 32, 37, 40, 48, 49, 64, 70, 150])
+@pytest.mark.parametrize("n", [1, 3, 4, 8, 10, 12, 16, 20, 23, 24, 28, 32, 37, 40, 48, 49, 64, 70, 150, 220, 256])
 @pytest.mark.parametrize("mode", [2, 3], ids=["token-vector", "token-blocked"])
 def test_compressed_path_all_kernel_shapes(oracle, n, mode):
     """Both token kernels for every shape whose operator table fits LDS (mode 3 falls back to the vector
@@ -303,7 +303,7 @@ def test_bad_arguments_raise(hmm_params):
         f.forward(pi, T, E[:, :2])           # chunk alphabet (3) larger than S=2
     with pytest.raises(ValueError):
         Forwarder.from_array(np.array([0, 5], dtype=np.uint8), 3)
-    big = synth.random_hmm(193, 3, 1)
+    big = synth.random_hmm(257, 3, 1)
     with pytest.raises(ValueError):
         f.forward(*big)                      # N beyond the largest built kernel is refused loudly
 
@@ -353,7 +353,7 @@ def test_maximum_likelihood_estimate_improves(hmm_params_file, example_pairs):
     assert len(log.getvalue().splitlines()[0].split("\t")) == 3
 
 
-@pytest.mark.parametrize("n", [70, 100, 150, 192])
+@pytest.mark.parametrize("n", [70, 100, 150, 192, 210, 256])
 @pytest.mark.parametrize("mode", [2, 4], ids=["tokens", "raw"])
 def test_matvec_chain_kernel_large_n(oracle, n, mode):
     """N > 64 with one segment per chunk (pinned by the 'vector' modes): the mat-vec chain kernel, batch of 3."""
