@@ -443,6 +443,9 @@ struct BigVec {
     // every pass covers 4 WAVES rows and the passes tile NP = 16 NT rows exactly; <= 48 operator doubles per lane
     static constexpr int WAVES = NT == 3 ? 12 : NT == 14 ? 14 : NT > 12 ? 16 : 8;
     static constexpr bool PIPELINED = NT <= 10;      // beyond that the double set of operator registers would spill
+    // not pipelined: all of a step's loads are issued before its first use while they fit the registers (NT = 12;
+    // measured at NT = 10: loading pass by pass instead costs 50 %), pass by pass beyond
+    static constexpr bool LOAD_AHEAD = !PIPELINED && NT <= 12;
 };
 
 template <int NT>
@@ -507,13 +510,17 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     }
     for (int t = 1; t < len; ++t) {
         const double *An = Ct + (size_t)(BigVec<NT>::PIPELINED ? tok_next : tok) * NP * NP;
+        if constexpr (BigVec<NT>::LOAD_AHEAD) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) BV_LOAD(ps, An);
+        }
         const int tok_after = t + 2 < len ? seg_token(tokp, wide, t + 2) : tok_next;
         const double *xc = &xs[cur][W * lm];   // x of step t-1 as stored (before its scale): the scale is applied to the dot products
         double mx = 0.0;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int row = ps * ROWS_PER_PASS + wave * 4 + lg;
-            if constexpr (!BigVec<NT>::PIPELINED) BV_LOAD(ps, An);   // (the compiler overlaps passes as far as registers allow)
+            if constexpr (!BigVec<NT>::PIPELINED && !BigVec<NT>::LOAD_AHEAD) BV_LOAD(ps, An);
             double p = 0.0;
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) {
