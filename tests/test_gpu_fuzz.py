@@ -50,3 +50,39 @@ def test_random_dispatch(oracle, case):
             want = oracle.forward_scaled(*hmms[b], c)
             g = got[b, f]
             assert (g == 0.0 and want == 0.0) or rel_err(g, want) < 1e-11, (case, n, nsym, mode, seg, B, lens, kernels, b, f, g, want)
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_random_split_state(oracle, case):
+    """imc_forward_state under the same random dispatch: a random alignment cut at random points, vector from the
+    first piece and operators from the rest, recombined and checked against the oracle on the whole alignment."""
+    from imcoalhmm_amd.hmm import combine_states, forward_states
+    rng = np.random.default_rng(7000 + case)
+    L = _capi.lib()
+    n = int(rng.choice([1, 2, 5, 10, 16, 20, 24, 27, 40, 64, 65, 128, 150, 200]))
+    nsym = int(rng.choice([2, 3, 3, 4]))
+    mode = int(rng.integers(0, 6))
+    seg = int(rng.choice([0, 0, 16, 256]))
+    B = int(rng.choice([1, 2]))
+    total = int(rng.choice([50, 3000, 12000 if n > 64 else 80000]))
+    whole = _chunk(rng, nsym, total)
+    cuts = sorted(set([0, total] + [int(x) for x in rng.integers(1, total, size=int(rng.integers(1, 4)))]))
+    pieces = [whole[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    hmms = [synth.random_hmm(n, nsym, seed=case * 10 + b, stay=float(rng.choice([0.5, 0.9, 0.999]))) for b in range(B)]
+    pis, Ts, Es = (np.stack([h[k] for h in hmms]) for k in range(3))
+    try:
+        _capi.check(L.imc_set_compression(mode))
+        _capi.check(L.imc_dictionary_reset())
+        _capi.check(L.imc_set_segment_length(seg))
+        fw = [Forwarder.from_array(p, nsym) for p in pieces]
+        vec, vexp = forward_states([fw[0].handle], pis, Ts, Es, False)
+        if len(fw) > 1:
+            ops, oexp = forward_states([f.handle for f in fw[1:]], pis, Ts, Es, True)
+        kernels = _capi.last_plan()["kernels"]
+    finally:
+        L.imc_set_compression(1)
+        L.imc_set_segment_length(0)
+    for b in range(B):
+        got = combine_states(vec[b, 0], vexp[b, 0], ops[b] if len(fw) > 1 else [], oexp[b] if len(fw) > 1 else [])
+        want = oracle.forward_scaled(*hmms[b], whole)
+        assert rel_err(got, want) < 1e-11, (case, n, nsym, mode, seg, B, cuts, kernels, b, got, want)
