@@ -626,7 +626,10 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
                     size_t sg = std::max<size_t>(16, round_up((size_t)std::ceil((double)total / target), 16));
                     for (int it = 0; it < 256 && rows_used(sg) > target; ++it) sg += 16;
                     const double used = rows_used(sg);
-                    const double c = std::ceil(used * B / rows) * (double)sg * (Z2WAVES / 4.0) * step_cycles;
+                    // per round of workgroups: the main loop, plus the table rebuild and the 5-level in-kernel fold
+                    const double fixed = (double)(gr.A - S) * (400.0 + (double)kc->NP * kc->NP * kc->NP / 64.0)
+                                         + 5.0 * (Z2WAVES / 4.0) * step_cycles;
+                    const double c = std::ceil(used * B / rows) * ((double)sg * (Z2WAVES / 4.0) * step_cycles + fixed);
                     if (c < cost_blk) { cost_blk = c; seg_blk = sg; slots = used; }
                 }
                 if (std::getenv("IMC_DEBUG"))
