@@ -460,6 +460,377 @@ static double matvec_step_cycles(double np2, int alphabet)
     return np2 / 3.0 * std::min(2.2, 1.0 + 0.03 * std::max(0.0, table_mb - 6.0));
 }
 
+// Builds one launch plan in phases; every phase reads what the earlier ones left in the members.
+struct PlanBuilder {
+    const imc_obs *const *chunks;
+    int n_chunks, N, S, B;
+    bool op_mode;                       // imc_forward_state(as_operator): no segment is a chunk's "first"
+    KernelChoice *kc;
+    std::unique_ptr<Plan> p;
+    bool big = false;                   // GEMM-chain / mat-vec chain kernels (global-memory operator table)
+    std::vector<int> chunk_group;       // chunk -> index into p->groups
+    std::vector<SegDesc> segs;          // all segments, chunk order
+    std::vector<uint8_t> seg_first;
+    std::vector<uint32_t> chunk_seg;    // chunk -> first segment (n_chunks + 1 entries)
+    std::vector<VecDesc> vecs;          // level-0 vectors
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> chunk_units;
+    std::vector<uint32_t> chunk_unit, unit_vec0;
+    std::vector<uint8_t> unit_first;
+    struct HostLevel { std::vector<uint32_t> chunk_seg, vec0; std::vector<uint8_t> first; std::vector<ChainDesc> chains; uint32_t n_vecs; };
+    std::vector<HostLevel> hl;          // stitch hierarchy, level 0 = propagate output
+    std::vector<int32_t> final_vec;     // chunk -> its single remaining unit at the last level (-1: empty chunk)
+
+    void assign_groups()
+    {
+        // ---- assign chunks to launch groups: plain, or (dictionary, level) ----
+        big = kc->R == 0;
+        int a_max = 0;   // largest alphabet whose operator table fits LDS for this N (no limit on the large-N path)
+        if (big) a_max = imc::kMaxAlphabet;
+        else
+            for (int A = 1; A <= imc::kMaxAlphabet; ++A)
+                if (kc->zip_lds(A) <= LDS_BUDGET || (kc->zip2 && g.kernel_pref != 1 && kc->zip2_lds(A) <= LDS_BUDGET)) a_max = A;
+        // One dictionary level per dictionary: the deepest level is not always the best - every workgroup rebuilds
+        // the operator table per evaluation ((A - S) dependent small products), which dominates on short inputs.
+        // Estimate: table build + main loop with all 16-lane rows of the machine busy.
+        std::map<const DictDev *, int> dict_level;
+        if (g.compression) {
+            std::map<const DictDev *, std::vector<int>> by_dict;
+            for (int f = 0; f < n_chunks; ++f)
+                if (chunks[f]->dict && chunks[f]->nsym == S) by_dict[chunks[f]->dict.get()].push_back(f);
+            for (auto &kv : by_dict) {
+                double best = 1e300;
+                int best_l = -1;
+                for (int l = 0; l < imc::kNumLevels; ++l) {
+                    const imc_obs *o0 = chunks[kv.second[0]];
+                    if (!(o0->alphabet[l] <= a_max && o0->alphabet[l] > o0->nsym && o0->d_tok[l])) continue;
+                    if (big && (size_t)B * o0->alphabet[l] * kc->NP * kc->NP * 8 > CTAB_BUDGET) continue;   // table too large
+                    double toks = 0.0;
+                    for (int f : kv.second) toks += (double)chunks[f]->ntok[l];
+                    const double n3 = (double)kc->NP * kc->NP * kc->NP;
+                    double c_tab, c_main;   // cycles
+                    if (big) {   // one GEMM per step per workgroup (~0.027 n^3 cycles measured at N=150), table built by depth
+                        const double gemm = 0.027 * n3 + 20000.0;
+                        c_tab = ((o0->alphabet[l] - S) / (double)g.cus + 12.0) * gemm;   // one workgroup per token, ~12 depth launches
+                        c_main = std::max(16.0, toks * B / (double)g.cus) * gemm;
+                        double lmax = 0.0;   // or the mat-vec chain kernel, when no chunk needs splitting
+                        for (int f : kv.second) lmax = std::max(lmax, (double)chunks[f]->ntok[l]);
+                        const double np2 = (double)kc->NP * kc->NP;
+                        const double c_vec = std::max(lmax * (np2 / 8.0 + 1500.0), toks * B / (double)g.cus * matvec_step_cycles(np2, o0->alphabet[l]));
+                        if (!op_mode && (g.kernel_pref == 1 || (g.kernel_pref == 0 && c_vec < c_main))) c_main = c_vec;
+                    } else {     // ~5200 cycles per row-step at N=20; every workgroup rebuilds the table
+                        c_tab = (o0->alphabet[l] - S) * (400.0 + n3 / 64.0);
+                        c_main = std::max(16.0, toks * B / ((double)g.cus * 32.0)) * 0.65 * n3;
+                    }
+                    if (c_tab + c_main < best) { best = c_tab + c_main; best_l = l; }
+                }
+                if (const char *fl = std::getenv("IMC_FORCE_LEVEL")) {   // experiments only: pin the dictionary level index
+                    const int l = std::atoi(fl);
+                    const imc_obs *o0 = chunks[kv.second[0]];
+                    if (l >= 0 && l < imc::kNumLevels && o0->alphabet[l] <= a_max && o0->alphabet[l] > o0->nsym && o0->d_tok[l]) best_l = l;
+                }
+                dict_level[kv.first] = best_l;
+            }
+        }
+        chunk_group.assign(n_chunks, -1);
+        for (int f = 0; f < n_chunks; ++f) {
+            const imc_obs *o = chunks[f];
+            int level = -1;
+            if (g.compression && o->dict && o->nsym == S) {
+                auto it = dict_level.find(o->dict.get());
+                if (it != dict_level.end()) level = it->second;
+            }
+            int gi = -1;
+            for (size_t q = 0; q < p->groups.size(); ++q) {
+                Group &gr = p->groups[q];
+                if (level < 0 ? !gr.zip : (gr.zip && gr.level == level && gr.dict == o->dict)) gi = (int)q;
+            }
+            if (gi < 0) {
+                Group gr;
+                gr.zip = level >= 0;
+                gr.level = level;
+                gr.big = big;
+                gr.A = S;
+                if (gr.zip) { gr.dict = o->dict; gr.A = o->alphabet[level]; }
+                p->groups.push_back(gr);
+                gi = (int)p->groups.size() - 1;
+            }
+            p->groups[gi].chunks.push_back(f);
+            chunk_group[f] = gi;
+        }
+    }
+
+    void choose_segment_lengths()
+    {
+        // ---- segment length per group ----
+        for (Group &gr : p->groups) {
+            std::vector<size_t> lens;
+            for (int f : gr.chunks) lens.push_back(gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L);
+            if (gr.big) {
+                // every segment costs N^3 per step whatever the split (one workgroup = one CU's worth of LDS), so
+                // one equal-length segment per CU is both balanced and the fewest operators for the stitch
+                size_t total = 0;
+                for (size_t L : lens) total += L;
+                const size_t per_cu = std::max<size_t>(1, std::min<size_t>(LDS_BUDGET / kc->big_lds, (size_t)32 / (size_t)kc->G));
+                const size_t target = std::max<size_t>(1, (size_t)g.cus * per_cu / ((size_t)B * kc->big_nslab));
+                gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
+                // ... unless there are so many (chunk, parameter set) chains that no chunk needs splitting: then
+                // the mat-vec chain kernel streams NP^2 doubles per step instead of a GEMM (measured at N=150, 64 x 32
+                // chains: 8900 cycles per step per CU, i.e. ~12 TB/s of operator reads over the whole chip)
+                size_t lmax = 0;
+                for (size_t L : lens) lmax = std::max(lmax, L);
+                const double np2 = (double)kc->NP * kc->NP, per_cu_steps = (double)total * B / (double)g.cus;
+                const double cost_vec = std::max((double)lmax * (np2 / 8.0 + 1500.0), per_cu_steps * matvec_step_cycles(np2, gr.A));
+                const double cost_gemm = std::max(16.0, per_cu_steps) * (0.027 * np2 * kc->NP + 20000.0);
+                if (std::getenv("IMC_DEBUG"))
+                    std::fprintf(stderr, "[imc] plan: GEMM chain seg %zu cost %.3g cycles; mat-vec chain cost %.3g cycles\n",
+                                 gr.seglen, cost_gemm, cost_vec);
+                if (!op_mode && (g.kernel_pref == 1 || (g.kernel_pref == 0 && cost_vec < cost_gemm))) {
+                    gr.bigvec = true;
+                    gr.seglen = std::max<size_t>(16, round_up(lmax, 16));
+                }
+            } else {
+                // vector kernel (one vector per lane group) ...
+                double cost_vec = 0.0;
+                size_t seg_vec;
+                if (gr.zip) {
+                    // LDS-bound: a workgroup of ZWAVES wavefronts serialises on one CU's LDS
+                    const double lds_cycles = ((double)kc->R * kc->NP / 2 + kc->NP / 2.0) * 4.0 + kc->R * 6.0 + 40.0;
+                    seg_vec = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * ZWAVES, lds_cycles * ZWAVES, &cost_vec);   // measured: 4600 cycles per wavefront-step at N=20
+                } else {
+                    // VALU-bound, minw wavefronts share a SIMD: measured 555 cycles per wavefront-column per SIMD at N=20
+                    seg_vec = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * 4.0 * kc->minw,
+                                            kc->minw * 1.7 * (4.0 * kc->R * kc->NP + 16.0), &cost_vec);
+                }
+                gr.seglen = seg_vec;
+                // ... or the register-blocked kernel (one operator per 16-lane row): fill every row of the machine
+                // once; first segments waste 1 - 1/N of their row, which the cost comparison accounts for
+                if (kc->zip2 && g.kernel_pref != 1 && kc->zip2_lds(gr.A) <= LDS_BUDGET && (gr.zip || S == gr.A)) {
+                    size_t total = 0;
+                    for (size_t L : lens) total += L;
+                    const double rows = (double)g.cus * Z2WAVES * 4;
+                    const double rb = kc->NP / 4.0;
+                    const double step_cycles = 5.8 * rb * rb * kc->NP;          // per wavefront-step (4 rows), measured ~2900 at N=20
+                    size_t seg_blk = 16;
+                    double slots = 0.0, cost_blk = 1e300;
+                    // a workgroup takes 32 consecutive segments of ONE chunk: rows are allocated per chunk in 32s
+                    auto rows_used = [&](size_t sg) {
+                        double r = 0.0;
+                        for (size_t L : lens) r += std::ceil(std::ceil((double)L / (double)sg) / Z2SLOTS) * Z2SLOTS;
+                        return r;
+                    };
+                    for (int rounds = 1; rounds <= 16; ++rounds) {               // fill the machine's rows `rounds` times
+                        const double target = std::max((double)Z2SLOTS, std::floor(rows * rounds / B));
+                        size_t sg = std::max<size_t>(16, round_up((size_t)std::ceil((double)total / target), 16));
+                        for (int it = 0; it < 256 && rows_used(sg) > target; ++it) sg += 16;
+                        const double used = rows_used(sg);
+                        // per round of workgroups: the main loop, plus the table rebuild and the 5-level in-kernel fold
+                        const double fixed = (double)(gr.A - S) * (400.0 + (double)kc->NP * kc->NP * kc->NP / 64.0)
+                                             + 5.0 * (Z2WAVES / 4.0) * step_cycles;
+                        const double c = std::ceil(used * B / rows) * ((double)sg * (Z2WAVES / 4.0) * step_cycles + fixed);
+                        if (c < cost_blk) { cost_blk = c; seg_blk = sg; slots = used; }
+                    }
+                    if (std::getenv("IMC_DEBUG"))
+                        std::fprintf(stderr, "[imc] plan: vector kernel seg %zu cost %.3g cycles; blocked kernel seg %zu slots %.0f cost %.3g cycles\n",
+                                     seg_vec, cost_vec, seg_blk, slots, cost_blk);
+                    const bool vec_fits = !gr.zip || kc->zip_lds(gr.A) <= LDS_BUDGET;   // the table may only fit the blocked kernel
+                    if (g.kernel_pref == 2 || cost_blk < cost_vec || !vec_fits) { gr.zip2 = true; gr.seglen = seg_blk; }
+                }
+            }
+            if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);   // tests: force stitching
+            if (gr.bigvec)
+                for (size_t L : lens) gr.bigvec = gr.bigvec && L <= gr.seglen && !op_mode;
+        }
+    }
+
+    void cut_segments()
+    {
+        // ---- segments in chunk order ----
+        chunk_seg.assign(n_chunks + 1, 0);
+        for (int f = 0; f < n_chunks; ++f) {
+            chunk_seg[f] = (uint32_t)segs.size();
+            const Group &gr = p->groups[chunk_group[f]];
+            const size_t L = gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L;
+            const uint8_t *base = gr.zip ? chunks[f]->d_tok[gr.level] : chunks[f]->d_sym;
+            if (!L) continue;
+            const size_t K0 = (L + gr.seglen - 1) / gr.seglen;
+            const size_t sl = round_up((L + K0 - 1) / K0, 16);   // equalised, multiple of 16
+            for (size_t off = 0, k = 0; off < L; off += sl, ++k) {
+                const bool wide = gr.zip && chunks[f]->wide[gr.level];
+                const bool fst = k == 0 && !op_mode;   // operator mode: the chunk's own first segment is an operator too
+                segs.push_back(SegDesc{base + off * (wide ? 2 : 1), (uint32_t)std::min(sl, L - off),
+                                       (fst ? SEG_FIRST : 0u) | (wide ? SEG_WIDE : 0u)});
+                seg_first.push_back(fst);
+            }
+        }
+        chunk_seg[n_chunks] = (uint32_t)segs.size();
+    }
+
+    int make_units()
+    {
+        // ---- stitch units and their vectors, contiguous per group ----
+        // A unit is what the stitch hierarchy sees at level 0: a segment, or (blocked kernel) a workgroup's
+        // run of up to 32 consecutive segments of one chunk, already folded inside the kernel.
+        chunk_units.assign(n_chunks, {});   // per chunk: (seg0, nsegs)
+        for (int f = 0; f < n_chunks; ++f) {
+            const Group &gr = p->groups[chunk_group[f]];
+            const uint32_t step = gr.zip2 ? (uint32_t)Z2SLOTS : 1u;
+            for (uint32_t sid = chunk_seg[f]; sid < chunk_seg[f + 1]; sid += step)
+                chunk_units[f].push_back({sid, std::min(step, chunk_seg[f + 1] - sid)});
+        }
+        chunk_unit.assign(n_chunks + 1, 0);
+        for (int f = 0; f < n_chunks; ++f) chunk_unit[f + 1] = chunk_unit[f] + (uint32_t)chunk_units[f].size();
+        unit_vec0.assign(chunk_unit[n_chunks], 0);
+        unit_first.assign(chunk_unit[n_chunks], 0);
+        for (Group &gr : p->groups) {
+            gr.vec_begin = (uint32_t)vecs.size();
+            for (int f : gr.chunks) {
+                gr.stream_len += gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L;
+                for (size_t u = 0; u < chunk_units[f].size(); ++u) {
+                    const uint32_t sid = chunk_units[f][u].first, ns = chunk_units[f][u].second;
+                    const uint32_t uid = chunk_unit[f] + (uint32_t)u;
+                    const bool fst = seg_first[sid] != 0;
+                    unit_first[uid] = fst;
+                    unit_vec0[uid] = (uint32_t)vecs.size();
+                    const int nv = fst ? 1 : N;
+                    for (int c = 0; c < nv; ++c) vecs.push_back(VecDesc{sid, (uint32_t)c});
+                    if (gr.big) { gr.seg_ids.push_back(sid); gr.seg_out.push_back(unit_vec0[uid]); }
+                    if (gr.zip2) gr.blocks.push_back(Z2Block{sid, ns, unit_vec0[uid], fst ? 1u : 0u});
+                    for (uint32_t q2 = 0; q2 < ns; ++q2)
+                        gr.vsteps += (uint64_t)((seg_first[sid + q2] && !gr.zip2) ? 1 : N) * segs[sid + q2].len;
+                }
+            }
+            gr.n_vecs = (uint32_t)vecs.size() - gr.vec_begin;
+        }
+        if (vecs.size() >= (size_t)UINT32_MAX / 2) return fail(IMC_ERR_ARG, "too many vectors in one call");
+        p->n_segs = (uint32_t)segs.size();
+        p->n_vecs = (uint32_t)vecs.size();
+        p->pstride = round_up((size_t)kc->NP + (size_t)kc->NP * kc->NP + (size_t)S * kc->NP, 2);
+
+        return IMC_OK;
+    }
+
+    void make_hierarchy()
+    {
+        // ---- stitch hierarchy: fold runs of g ~ sqrt(K) consecutive segments until one vector per chunk ----
+        hl.assign(1, HostLevel());
+        hl[0].chunk_seg = chunk_unit; hl[0].vec0 = unit_vec0; hl[0].first = unit_first; hl[0].n_vecs = p->n_vecs;
+        for (;;) {
+            const HostLevel &cur = hl.back();
+            uint32_t kmax = 0;
+            for (int f = 0; f < n_chunks; ++f) kmax = std::max(kmax, cur.chunk_seg[f + 1] - cur.chunk_seg[f]);
+            // a level whose chunks all hold one first-vector is final; level 0 operators always need one pass
+            if (kmax <= 1 && hl.size() > 1) break;
+            if (kmax == 0) break;
+            // ~3 levels: per level a chain costs g serial steps (~0.3 us each) plus two launches (~6 us)
+            const uint32_t gsz = kmax <= 16 ? kmax : std::max<uint32_t>(12, (uint32_t)std::ceil(std::cbrt((double)kmax)));
+            p->chain_steps += gsz;
+            HostLevel nx;
+            nx.chunk_seg.assign(n_chunks + 1, 0);
+            nx.n_vecs = 0;
+            for (int f = 0; f < n_chunks; ++f) {
+                nx.chunk_seg[f] = (uint32_t)nx.vec0.size();
+                const uint32_t s0 = cur.chunk_seg[f], s1 = cur.chunk_seg[f + 1];
+                for (uint32_t rb = s0; rb < s1; rb += gsz) {
+                    const uint32_t re = std::min(rb + gsz, s1);
+                    const bool fst = rb == s0 && !op_mode;
+                    nx.vec0.push_back(nx.n_vecs);
+                    nx.first.push_back(fst);
+                    const int nvv = fst ? 1 : N;
+                    for (int c = 0; c < nvv; ++c) nx.chains.push_back(ChainDesc{rb, re, (uint32_t)c, nx.n_vecs + c, fst ? 1u : 0u, 0u});
+                    nx.n_vecs += nvv;
+                }
+            }
+            nx.chunk_seg[n_chunks] = (uint32_t)nx.vec0.size();
+            const bool done = kmax <= gsz;
+            hl.push_back(std::move(nx));
+            if (done) break;
+        }
+        final_vec.assign(std::max(n_chunks, 1), -1);
+        for (int f = 0; f < n_chunks; ++f) {
+            const HostLevel &last = hl.back();
+            if (last.chunk_seg[f + 1] > last.chunk_seg[f]) final_vec[f] = (int32_t)last.vec0[last.chunk_seg[f]];
+        }
+
+    }
+
+    int upload(Plan **out)
+    {
+        while (g_plans.size() >= MAX_PLANS) { g_plans.back()->release(); g_plans.pop_back(); }
+
+        Plan *q = p.get();
+        auto up = [&](void **d, const void *h, size_t bytes) -> hipError_t {
+            hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 16));
+            if (e != hipSuccess) return e;
+            if (bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+            return e;
+        };
+        auto zalloc = [&](void **d, size_t bytes) -> hipError_t {
+            hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 16));
+            if (e == hipSuccess) e = hipMemset(*d, 0, std::max<size_t>(bytes, 16));   // padded operator columns stay 0
+            return e;
+        };
+        hipError_t e = hipSuccess;
+        if (e == hipSuccess) e = up((void **)&q->d_segs, segs.data(), segs.size() * sizeof(SegDesc));
+        if (e == hipSuccess) e = up((void **)&q->d_vecs, vecs.data(), vecs.size() * sizeof(VecDesc));
+        if (e == hipSuccess) e = up((void **)&q->d_final_vec, final_vec.data(), final_vec.size() * 4);
+        q->levels.resize(hl.size());
+        for (size_t l = 0; l < hl.size() && e == hipSuccess; ++l) {
+            Level &lv = q->levels[l];
+            lv.n_segs = (uint32_t)hl[l].vec0.size();
+            lv.n_vecs = hl[l].n_vecs;
+            lv.n_chains = (uint32_t)hl[l].chains.size();
+            const size_t nv = std::max<size_t>(lv.n_vecs, 1), ns = std::max<size_t>(lv.n_segs, 1);
+            e = up((void **)&lv.d_vec0, hl[l].vec0.data(), hl[l].vec0.size() * 4);
+            if (e == hipSuccess) e = up((void **)&lv.d_first, hl[l].first.data(), hl[l].first.size());
+            if (e == hipSuccess) e = up((void **)&lv.d_chains, hl[l].chains.data(), hl[l].chains.size() * sizeof(ChainDesc));
+            if (e == hipSuccess) e = zalloc((void **)&lv.d_P, (size_t)B * nv * kc->NP * 8);
+            if (e == hipSuccess) e = zalloc((void **)&lv.d_EX, (size_t)B * nv * 4);
+            if (e == hipSuccess) e = zalloc((void **)&lv.d_EMAX, (size_t)B * ns * 4);
+        }
+        for (Group &gr : q->groups) {
+            if (gr.zip2 && e == hipSuccess) e = up((void **)&gr.d_blocks, gr.blocks.data(), gr.blocks.size() * sizeof(Z2Block));
+            if (!gr.big || e != hipSuccess) continue;
+            const size_t np2 = (size_t)kc->NP * kc->NP;
+            // workgroup list: slabs of one segment 8 ids apart (same XCD -> they share the operator rows in L2)
+            {
+                std::vector<BigBlock> lin;
+                for (size_t i2 = 0; i2 < gr.seg_ids.size(); ++i2) {
+                    const bool fst = seg_first[gr.seg_ids[i2]] != 0;
+                    for (int sl = 0; sl < (fst ? 1 : kc->big_nslab); ++sl)
+                        lin.push_back(BigBlock{gr.seg_ids[i2], (uint32_t)sl, gr.seg_out[i2], 0u});
+                }
+                // lin is segment-major; re-deal non-first segments in tiles of 8 segments x nslab
+                gr.big_blocks.clear();
+                std::vector<BigBlock> firsts, rest;
+                for (const BigBlock &bb : lin) (seg_first[bb.seg] ? firsts : rest).push_back(bb);
+                const size_t ns = (size_t)kc->big_nslab;
+                for (size_t base = 0; base < rest.size(); base += 8 * ns) {
+                    const size_t nseg = std::min<size_t>(8, (rest.size() - base) / ns);
+                    for (size_t sl = 0; sl < ns; ++sl)
+                        for (size_t k2 = 0; k2 < nseg; ++k2) gr.big_blocks.push_back(rest[base + k2 * ns + sl]);
+                }
+                for (const BigBlock &bb : firsts) gr.big_blocks.push_back(bb);
+            }
+            e = up((void **)&gr.d_big_blocks, gr.big_blocks.data(), gr.big_blocks.size() * sizeof(BigBlock));
+            if (e == hipSuccess) e = hipMalloc((void **)&gr.d_Ctab, (size_t)B * gr.A * np2 * 8);
+            if (e == hipSuccess) e = hipMalloc((void **)&gr.d_cex, (size_t)B * gr.A * 4 + 16);
+        }
+        if (e == hipSuccess) e = hipMalloc((void **)&q->d_params, (size_t)B * q->pstride * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&q->d_out, (size_t)B * std::max(n_chunks, 1) * 8);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_params, (size_t)B * q->pstride * 8, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_out, (size_t)B * std::max(n_chunks, 1) * 8, hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&q->h_out_dev, q->h_out, 0);
+        if (e != hipSuccess) {
+            q->release();
+            return fail(e == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
+                        std::string("plan allocation: ") + hipGetErrorString(e));
+        }
+        g_plans.push_front(std::move(p));
+        *out = q;
+        return IMC_OK;
+    }
+};
+
 int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, bool op_mode, Plan **out)
 {
     std::vector<uint64_t> key;
@@ -484,340 +855,18 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         for (int f = 0; f < n_chunks; ++f) tokens = tokens && chunks[f]->dict && chunks[f]->nsym == S;
         prefer_gemm = total / n_chunks >= 2.0e5 && (tokens || N > 40);
     }
+
     KernelChoice *kc = choose_kernel(N, prefer_gemm);
     if (!kc) return fail(IMC_ERR_ARG, "N exceeds the largest built kernel (" + std::to_string(IMC_MAX_N) + ")");
     auto p = std::make_unique<Plan>();
     p->key = key; p->kc = kc; p->N = N; p->S = S; p->B = B; p->n_chunks = n_chunks;
-
-    // ---- assign chunks to launch groups: plain, or (dictionary, level) ----
-    const bool big = kc->R == 0;
-    int a_max = 0;   // largest alphabet whose operator table fits LDS for this N (no limit on the large-N path)
-    if (big) a_max = imc::kMaxAlphabet;
-    else
-        for (int A = 1; A <= imc::kMaxAlphabet; ++A)
-            if (kc->zip_lds(A) <= LDS_BUDGET || (kc->zip2 && g.kernel_pref != 1 && kc->zip2_lds(A) <= LDS_BUDGET)) a_max = A;
-    // One dictionary level per dictionary: the deepest level is not always the best - every workgroup rebuilds
-    // the operator table per evaluation ((A - S) dependent small products), which dominates on short inputs.
-    // Estimate: table build + main loop with all 16-lane rows of the machine busy.
-    std::map<const DictDev *, int> dict_level;
-    if (g.compression) {
-        std::map<const DictDev *, std::vector<int>> by_dict;
-        for (int f = 0; f < n_chunks; ++f)
-            if (chunks[f]->dict && chunks[f]->nsym == S) by_dict[chunks[f]->dict.get()].push_back(f);
-        for (auto &kv : by_dict) {
-            double best = 1e300;
-            int best_l = -1;
-            for (int l = 0; l < imc::kNumLevels; ++l) {
-                const imc_obs *o0 = chunks[kv.second[0]];
-                if (!(o0->alphabet[l] <= a_max && o0->alphabet[l] > o0->nsym && o0->d_tok[l])) continue;
-                if (big && (size_t)B * o0->alphabet[l] * kc->NP * kc->NP * 8 > CTAB_BUDGET) continue;   // table too large
-                double toks = 0.0;
-                for (int f : kv.second) toks += (double)chunks[f]->ntok[l];
-                const double n3 = (double)kc->NP * kc->NP * kc->NP;
-                double c_tab, c_main;   // cycles
-                if (big) {   // one GEMM per step per workgroup (~0.027 n^3 cycles measured at N=150), table built by depth
-                    const double gemm = 0.027 * n3 + 20000.0;
-                    c_tab = ((o0->alphabet[l] - S) / (double)g.cus + 12.0) * gemm;   // one workgroup per token, ~12 depth launches
-                    c_main = std::max(16.0, toks * B / (double)g.cus) * gemm;
-                    double lmax = 0.0;   // or the mat-vec chain kernel, when no chunk needs splitting
-                    for (int f : kv.second) lmax = std::max(lmax, (double)chunks[f]->ntok[l]);
-                    const double np2 = (double)kc->NP * kc->NP;
-                    const double c_vec = std::max(lmax * (np2 / 8.0 + 1500.0), toks * B / (double)g.cus * matvec_step_cycles(np2, o0->alphabet[l]));
-                    if (!op_mode && (g.kernel_pref == 1 || (g.kernel_pref == 0 && c_vec < c_main))) c_main = c_vec;
-                } else {     // ~5200 cycles per row-step at N=20; every workgroup rebuilds the table
-                    c_tab = (o0->alphabet[l] - S) * (400.0 + n3 / 64.0);
-                    c_main = std::max(16.0, toks * B / ((double)g.cus * 32.0)) * 0.65 * n3;
-                }
-                if (c_tab + c_main < best) { best = c_tab + c_main; best_l = l; }
-            }
-            if (const char *fl = std::getenv("IMC_FORCE_LEVEL")) {   // experiments only: pin the dictionary level index
-                const int l = std::atoi(fl);
-                const imc_obs *o0 = chunks[kv.second[0]];
-                if (l >= 0 && l < imc::kNumLevels && o0->alphabet[l] <= a_max && o0->alphabet[l] > o0->nsym && o0->d_tok[l]) best_l = l;
-            }
-            dict_level[kv.first] = best_l;
-        }
-    }
-    std::vector<int> chunk_group(n_chunks, -1);
-    for (int f = 0; f < n_chunks; ++f) {
-        const imc_obs *o = chunks[f];
-        int level = -1;
-        if (g.compression && o->dict && o->nsym == S) {
-            auto it = dict_level.find(o->dict.get());
-            if (it != dict_level.end()) level = it->second;
-        }
-        int gi = -1;
-        for (size_t q = 0; q < p->groups.size(); ++q) {
-            Group &gr = p->groups[q];
-            if (level < 0 ? !gr.zip : (gr.zip && gr.level == level && gr.dict == o->dict)) gi = (int)q;
-        }
-        if (gi < 0) {
-            Group gr;
-            gr.zip = level >= 0;
-            gr.level = level;
-            gr.big = big;
-            gr.A = S;
-            if (gr.zip) { gr.dict = o->dict; gr.A = o->alphabet[level]; }
-            p->groups.push_back(gr);
-            gi = (int)p->groups.size() - 1;
-        }
-        p->groups[gi].chunks.push_back(f);
-        chunk_group[f] = gi;
-    }
-    // ---- segment length per group ----
-    for (Group &gr : p->groups) {
-        std::vector<size_t> lens;
-        for (int f : gr.chunks) lens.push_back(gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L);
-        if (gr.big) {
-            // every segment costs N^3 per step whatever the split (one workgroup = one CU's worth of LDS), so
-            // one equal-length segment per CU is both balanced and the fewest operators for the stitch
-            size_t total = 0;
-            for (size_t L : lens) total += L;
-            const size_t per_cu = std::max<size_t>(1, std::min<size_t>(LDS_BUDGET / kc->big_lds, (size_t)32 / (size_t)kc->G));
-            const size_t target = std::max<size_t>(1, (size_t)g.cus * per_cu / ((size_t)B * kc->big_nslab));
-            gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
-            // ... unless there are so many (chunk, parameter set) chains that no chunk needs splitting: then
-            // the mat-vec chain kernel streams NP^2 doubles per step instead of a GEMM (measured at N=150, 64 x 32
-            // chains: 8900 cycles per step per CU, i.e. ~12 TB/s of operator reads over the whole chip)
-            size_t lmax = 0;
-            for (size_t L : lens) lmax = std::max(lmax, L);
-            const double np2 = (double)kc->NP * kc->NP, per_cu_steps = (double)total * B / (double)g.cus;
-            const double cost_vec = std::max((double)lmax * (np2 / 8.0 + 1500.0), per_cu_steps * matvec_step_cycles(np2, gr.A));
-            const double cost_gemm = std::max(16.0, per_cu_steps) * (0.027 * np2 * kc->NP + 20000.0);
-            if (std::getenv("IMC_DEBUG"))
-                std::fprintf(stderr, "[imc] plan: GEMM chain seg %zu cost %.3g cycles; mat-vec chain cost %.3g cycles\n",
-                             gr.seglen, cost_gemm, cost_vec);
-            if (!op_mode && (g.kernel_pref == 1 || (g.kernel_pref == 0 && cost_vec < cost_gemm))) {
-                gr.bigvec = true;
-                gr.seglen = std::max<size_t>(16, round_up(lmax, 16));
-            }
-        } else {
-            // vector kernel (one vector per lane group) ...
-            double cost_vec = 0.0;
-            size_t seg_vec;
-            if (gr.zip) {
-                // LDS-bound: a workgroup of ZWAVES wavefronts serialises on one CU's LDS
-                const double lds_cycles = ((double)kc->R * kc->NP / 2 + kc->NP / 2.0) * 4.0 + kc->R * 6.0 + 40.0;
-                seg_vec = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * ZWAVES, lds_cycles * ZWAVES, &cost_vec);   // measured: 4600 cycles per wavefront-step at N=20
-            } else {
-                // VALU-bound, minw wavefronts share a SIMD: measured 555 cycles per wavefront-column per SIMD at N=20
-                seg_vec = choose_seglen(lens, N, B, kc->VPW, (double)g.cus * 4.0 * kc->minw,
-                                        kc->minw * 1.7 * (4.0 * kc->R * kc->NP + 16.0), &cost_vec);
-            }
-            gr.seglen = seg_vec;
-            // ... or the register-blocked kernel (one operator per 16-lane row): fill every row of the machine
-            // once; first segments waste 1 - 1/N of their row, which the cost comparison accounts for
-            if (kc->zip2 && g.kernel_pref != 1 && kc->zip2_lds(gr.A) <= LDS_BUDGET && (gr.zip || S == gr.A)) {
-                size_t total = 0;
-                for (size_t L : lens) total += L;
-                const double rows = (double)g.cus * Z2WAVES * 4;
-                const double rb = kc->NP / 4.0;
-                const double step_cycles = 5.8 * rb * rb * kc->NP;          // per wavefront-step (4 rows), measured ~2900 at N=20
-                size_t seg_blk = 16;
-                double slots = 0.0, cost_blk = 1e300;
-                // a workgroup takes 32 consecutive segments of ONE chunk: rows are allocated per chunk in 32s
-                auto rows_used = [&](size_t sg) {
-                    double r = 0.0;
-                    for (size_t L : lens) r += std::ceil(std::ceil((double)L / (double)sg) / Z2SLOTS) * Z2SLOTS;
-                    return r;
-                };
-                for (int rounds = 1; rounds <= 16; ++rounds) {               // fill the machine's rows `rounds` times
-                    const double target = std::max((double)Z2SLOTS, std::floor(rows * rounds / B));
-                    size_t sg = std::max<size_t>(16, round_up((size_t)std::ceil((double)total / target), 16));
-                    for (int it = 0; it < 256 && rows_used(sg) > target; ++it) sg += 16;
-                    const double used = rows_used(sg);
-                    // per round of workgroups: the main loop, plus the table rebuild and the 5-level in-kernel fold
-                    const double fixed = (double)(gr.A - S) * (400.0 + (double)kc->NP * kc->NP * kc->NP / 64.0)
-                                         + 5.0 * (Z2WAVES / 4.0) * step_cycles;
-                    const double c = std::ceil(used * B / rows) * ((double)sg * (Z2WAVES / 4.0) * step_cycles + fixed);
-                    if (c < cost_blk) { cost_blk = c; seg_blk = sg; slots = used; }
-                }
-                if (std::getenv("IMC_DEBUG"))
-                    std::fprintf(stderr, "[imc] plan: vector kernel seg %zu cost %.3g cycles; blocked kernel seg %zu slots %.0f cost %.3g cycles\n",
-                                 seg_vec, cost_vec, seg_blk, slots, cost_blk);
-                const bool vec_fits = !gr.zip || kc->zip_lds(gr.A) <= LDS_BUDGET;   // the table may only fit the blocked kernel
-                if (g.kernel_pref == 2 || cost_blk < cost_vec || !vec_fits) { gr.zip2 = true; gr.seglen = seg_blk; }
-            }
-        }
-        if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);   // tests: force stitching
-        if (gr.bigvec)
-            for (size_t L : lens) gr.bigvec = gr.bigvec && L <= gr.seglen && !op_mode;
-    }
-    // ---- segments in chunk order ----
-    std::vector<SegDesc> segs;
-    std::vector<uint8_t> seg_first;
-    std::vector<uint32_t> chunk_seg(n_chunks + 1, 0);
-    for (int f = 0; f < n_chunks; ++f) {
-        chunk_seg[f] = (uint32_t)segs.size();
-        const Group &gr = p->groups[chunk_group[f]];
-        const size_t L = gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L;
-        const uint8_t *base = gr.zip ? chunks[f]->d_tok[gr.level] : chunks[f]->d_sym;
-        if (!L) continue;
-        const size_t K0 = (L + gr.seglen - 1) / gr.seglen;
-        const size_t sl = round_up((L + K0 - 1) / K0, 16);   // equalised, multiple of 16
-        for (size_t off = 0, k = 0; off < L; off += sl, ++k) {
-            const bool wide = gr.zip && chunks[f]->wide[gr.level];
-            const bool fst = k == 0 && !op_mode;   // operator mode: the chunk's own first segment is an operator too
-            segs.push_back(SegDesc{base + off * (wide ? 2 : 1), (uint32_t)std::min(sl, L - off),
-                                   (fst ? SEG_FIRST : 0u) | (wide ? SEG_WIDE : 0u)});
-            seg_first.push_back(fst);
-        }
-    }
-    chunk_seg[n_chunks] = (uint32_t)segs.size();
-    // ---- stitch units and their vectors, contiguous per group ----
-    // A unit is what the stitch hierarchy sees at level 0: a segment, or (blocked kernel) a workgroup's
-    // run of up to 32 consecutive segments of one chunk, already folded inside the kernel.
-    std::vector<VecDesc> vecs;
-    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> chunk_units(n_chunks);   // per chunk: (seg0, nsegs)
-    for (int f = 0; f < n_chunks; ++f) {
-        const Group &gr = p->groups[chunk_group[f]];
-        const uint32_t step = gr.zip2 ? (uint32_t)Z2SLOTS : 1u;
-        for (uint32_t sid = chunk_seg[f]; sid < chunk_seg[f + 1]; sid += step)
-            chunk_units[f].push_back({sid, std::min(step, chunk_seg[f + 1] - sid)});
-    }
-    std::vector<uint32_t> chunk_unit(n_chunks + 1, 0);
-    for (int f = 0; f < n_chunks; ++f) chunk_unit[f + 1] = chunk_unit[f] + (uint32_t)chunk_units[f].size();
-    std::vector<uint32_t> unit_vec0(chunk_unit[n_chunks], 0);
-    std::vector<uint8_t> unit_first(chunk_unit[n_chunks], 0);
-    for (Group &gr : p->groups) {
-        gr.vec_begin = (uint32_t)vecs.size();
-        for (int f : gr.chunks) {
-            gr.stream_len += gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L;
-            for (size_t u = 0; u < chunk_units[f].size(); ++u) {
-                const uint32_t sid = chunk_units[f][u].first, ns = chunk_units[f][u].second;
-                const uint32_t uid = chunk_unit[f] + (uint32_t)u;
-                const bool fst = seg_first[sid] != 0;
-                unit_first[uid] = fst;
-                unit_vec0[uid] = (uint32_t)vecs.size();
-                const int nv = fst ? 1 : N;
-                for (int c = 0; c < nv; ++c) vecs.push_back(VecDesc{sid, (uint32_t)c});
-                if (gr.big) { gr.seg_ids.push_back(sid); gr.seg_out.push_back(unit_vec0[uid]); }
-                if (gr.zip2) gr.blocks.push_back(Z2Block{sid, ns, unit_vec0[uid], fst ? 1u : 0u});
-                for (uint32_t q2 = 0; q2 < ns; ++q2)
-                    gr.vsteps += (uint64_t)((seg_first[sid + q2] && !gr.zip2) ? 1 : N) * segs[sid + q2].len;
-            }
-        }
-        gr.n_vecs = (uint32_t)vecs.size() - gr.vec_begin;
-    }
-    if (vecs.size() >= (size_t)UINT32_MAX / 2) return fail(IMC_ERR_ARG, "too many vectors in one call");
-    p->n_segs = (uint32_t)segs.size();
-    p->n_vecs = (uint32_t)vecs.size();
-    p->pstride = round_up((size_t)kc->NP + (size_t)kc->NP * kc->NP + (size_t)S * kc->NP, 2);
-
-    // ---- stitch hierarchy: fold runs of g ~ sqrt(K) consecutive segments until one vector per chunk ----
-    struct HostLevel { std::vector<uint32_t> chunk_seg, vec0; std::vector<uint8_t> first; std::vector<ChainDesc> chains; uint32_t n_vecs; };
-    std::vector<HostLevel> hl(1);
-    hl[0].chunk_seg = chunk_unit; hl[0].vec0 = unit_vec0; hl[0].first = unit_first; hl[0].n_vecs = p->n_vecs;
-    for (;;) {
-        const HostLevel &cur = hl.back();
-        uint32_t kmax = 0;
-        for (int f = 0; f < n_chunks; ++f) kmax = std::max(kmax, cur.chunk_seg[f + 1] - cur.chunk_seg[f]);
-        // a level whose chunks all hold one first-vector is final; level 0 operators always need one pass
-        if (kmax <= 1 && hl.size() > 1) break;
-        if (kmax == 0) break;
-        // ~3 levels: per level a chain costs g serial steps (~0.3 us each) plus two launches (~6 us)
-        const uint32_t gsz = kmax <= 16 ? kmax : std::max<uint32_t>(12, (uint32_t)std::ceil(std::cbrt((double)kmax)));
-        p->chain_steps += gsz;
-        HostLevel nx;
-        nx.chunk_seg.assign(n_chunks + 1, 0);
-        nx.n_vecs = 0;
-        for (int f = 0; f < n_chunks; ++f) {
-            nx.chunk_seg[f] = (uint32_t)nx.vec0.size();
-            const uint32_t s0 = cur.chunk_seg[f], s1 = cur.chunk_seg[f + 1];
-            for (uint32_t rb = s0; rb < s1; rb += gsz) {
-                const uint32_t re = std::min(rb + gsz, s1);
-                const bool fst = rb == s0 && !op_mode;
-                nx.vec0.push_back(nx.n_vecs);
-                nx.first.push_back(fst);
-                const int nvv = fst ? 1 : N;
-                for (int c = 0; c < nvv; ++c) nx.chains.push_back(ChainDesc{rb, re, (uint32_t)c, nx.n_vecs + c, fst ? 1u : 0u, 0u});
-                nx.n_vecs += nvv;
-            }
-        }
-        nx.chunk_seg[n_chunks] = (uint32_t)nx.vec0.size();
-        const bool done = kmax <= gsz;
-        hl.push_back(std::move(nx));
-        if (done) break;
-    }
-    std::vector<int32_t> final_vec(std::max(n_chunks, 1), -1);
-    for (int f = 0; f < n_chunks; ++f) {
-        const HostLevel &last = hl.back();
-        if (last.chunk_seg[f + 1] > last.chunk_seg[f]) final_vec[f] = (int32_t)last.vec0[last.chunk_seg[f]];
-    }
-
-    while (g_plans.size() >= MAX_PLANS) { g_plans.back()->release(); g_plans.pop_back(); }
-
-    Plan *q = p.get();
-    auto up = [&](void **d, const void *h, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 16));
-        if (e != hipSuccess) return e;
-        if (bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
-        return e;
-    };
-    auto zalloc = [&](void **d, size_t bytes) -> hipError_t {
-        hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 16));
-        if (e == hipSuccess) e = hipMemset(*d, 0, std::max<size_t>(bytes, 16));   // padded operator columns stay 0
-        return e;
-    };
-    hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = up((void **)&q->d_segs, segs.data(), segs.size() * sizeof(SegDesc));
-    if (e == hipSuccess) e = up((void **)&q->d_vecs, vecs.data(), vecs.size() * sizeof(VecDesc));
-    if (e == hipSuccess) e = up((void **)&q->d_final_vec, final_vec.data(), final_vec.size() * 4);
-    q->levels.resize(hl.size());
-    for (size_t l = 0; l < hl.size() && e == hipSuccess; ++l) {
-        Level &lv = q->levels[l];
-        lv.n_segs = (uint32_t)hl[l].vec0.size();
-        lv.n_vecs = hl[l].n_vecs;
-        lv.n_chains = (uint32_t)hl[l].chains.size();
-        const size_t nv = std::max<size_t>(lv.n_vecs, 1), ns = std::max<size_t>(lv.n_segs, 1);
-        e = up((void **)&lv.d_vec0, hl[l].vec0.data(), hl[l].vec0.size() * 4);
-        if (e == hipSuccess) e = up((void **)&lv.d_first, hl[l].first.data(), hl[l].first.size());
-        if (e == hipSuccess) e = up((void **)&lv.d_chains, hl[l].chains.data(), hl[l].chains.size() * sizeof(ChainDesc));
-        if (e == hipSuccess) e = zalloc((void **)&lv.d_P, (size_t)B * nv * kc->NP * 8);
-        if (e == hipSuccess) e = zalloc((void **)&lv.d_EX, (size_t)B * nv * 4);
-        if (e == hipSuccess) e = zalloc((void **)&lv.d_EMAX, (size_t)B * ns * 4);
-    }
-    for (Group &gr : q->groups) {
-        if (gr.zip2 && e == hipSuccess) e = up((void **)&gr.d_blocks, gr.blocks.data(), gr.blocks.size() * sizeof(Z2Block));
-        if (!gr.big || e != hipSuccess) continue;
-        const size_t np2 = (size_t)kc->NP * kc->NP;
-        // workgroup list: slabs of one segment 8 ids apart (same XCD -> they share the operator rows in L2)
-        {
-            std::vector<BigBlock> lin;
-            for (size_t i2 = 0; i2 < gr.seg_ids.size(); ++i2) {
-                const bool fst = seg_first[gr.seg_ids[i2]] != 0;
-                for (int sl = 0; sl < (fst ? 1 : kc->big_nslab); ++sl)
-                    lin.push_back(BigBlock{gr.seg_ids[i2], (uint32_t)sl, gr.seg_out[i2], 0u});
-            }
-            // lin is segment-major; re-deal non-first segments in tiles of 8 segments x nslab
-            gr.big_blocks.clear();
-            std::vector<BigBlock> firsts, rest;
-            for (const BigBlock &bb : lin) (seg_first[bb.seg] ? firsts : rest).push_back(bb);
-            const size_t ns = (size_t)kc->big_nslab;
-            for (size_t base = 0; base < rest.size(); base += 8 * ns) {
-                const size_t nseg = std::min<size_t>(8, (rest.size() - base) / ns);
-                for (size_t sl = 0; sl < ns; ++sl)
-                    for (size_t k2 = 0; k2 < nseg; ++k2) gr.big_blocks.push_back(rest[base + k2 * ns + sl]);
-            }
-            for (const BigBlock &bb : firsts) gr.big_blocks.push_back(bb);
-        }
-        e = up((void **)&gr.d_big_blocks, gr.big_blocks.data(), gr.big_blocks.size() * sizeof(BigBlock));
-        if (e == hipSuccess) e = hipMalloc((void **)&gr.d_Ctab, (size_t)B * gr.A * np2 * 8);
-        if (e == hipSuccess) e = hipMalloc((void **)&gr.d_cex, (size_t)B * gr.A * 4 + 16);
-    }
-    if (e == hipSuccess) e = hipMalloc((void **)&q->d_params, (size_t)B * q->pstride * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&q->d_out, (size_t)B * std::max(n_chunks, 1) * 8);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_params, (size_t)B * q->pstride * 8, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_out, (size_t)B * std::max(n_chunks, 1) * 8, hipHostMallocMapped);
-    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&q->h_out_dev, q->h_out, 0);
-    if (e != hipSuccess) {
-        q->release();
-        return fail(e == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
-                    std::string("plan allocation: ") + hipGetErrorString(e));
-    }
-    g_plans.push_front(std::move(p));
-    *out = q;
-    return IMC_OK;
+    PlanBuilder pb{chunks, n_chunks, N, S, B, op_mode, kc, std::move(p)};
+    pb.assign_groups();
+    pb.choose_segment_lengths();
+    pb.cut_segments();
+    if (int rc = pb.make_units()) return rc;
+    pb.make_hierarchy();
+    return pb.upload(out);
 }
 
 int check_args(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, const double *pis,
