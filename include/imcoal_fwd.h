@@ -25,6 +25,11 @@
  * Threads / processes: no HIP call is made before the first compute/create call, and the device
  * context is re-created lazily per PID, so Forwarders may be built inside multiprocessing
  * children as mcmc.py:112-121 does.  Calls are serialised internally by one mutex.
+ *
+ * Environment (diagnostics only, read when a plan is built / the context is created):
+ *   IMC_DEBUG=1        print the planner's cost estimates to stderr
+ *   IMC_FORCE_LEVEL=k  pin the pair-dictionary level index (experiments; ignored if the level does not fit)
+ *   IMC_GRAPH=1        replay each plan as a hipGraph (measured: no gain)
  */
 #ifndef IMCOAL_FWD_H
 #define IMCOAL_FWD_H
