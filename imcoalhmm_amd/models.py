@@ -290,6 +290,7 @@ class _Through(object):
                     slots[key] = len(group)
                     group.append(Q * dt)
         self.stacks = {size: expm(np.stack(group)) for size, group in members.items()}
+        self._gathered = {}
         self.where = []            # per interval: (size, positions (B,), projection)
         for i in range(len(systems[0].pieces)):
             pos = np.array([slots[(b, id(sy.pieces[i][0]), float(sy.pieces[i][1]))]
@@ -301,7 +302,13 @@ class _Through(object):
         size, pos, proj = self.where[i]
         stack = self.stacks[size]
         if proj is None:
-            return stack[pos[:, None, None], rows[None, :, None], cols[None, None, :]]
+            # one gather per (matrix size, row class, column class) for ALL matrices of the stack; an interval
+            # then only picks its systems' positions (the class index arrays live on the StateSpace objects)
+            key = (size, id(rows), id(cols))
+            blocks = self._gathered.get(key)
+            if blocks is None:
+                blocks = self._gathered[key] = stack[:, rows[:, None], cols[None, :]]
+            return blocks[pos]
         return stack[pos[:, None], rows[None, :]] @ proj[:, cols]
 
 
