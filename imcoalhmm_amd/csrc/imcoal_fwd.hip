@@ -280,6 +280,7 @@ struct KernelChoice {
     void (*big_table_raw)(BigArgs);
     void (*big_table_level)(BigArgs, const uint16_t *, int);
     void (*big_prop)(BigArgs, const BigBlock *);
+    int big_prop_waves;            // wavefronts per workgroup of big_prop (NT, or 8 for the dealt-tiles variant)
     void (*big_vec)(BigArgs, const BigBlock *, int, int);
     int big_vec_waves;
     int big_nslab;
@@ -295,7 +296,7 @@ KernelChoice make_kc()
 {
     constexpr int NP = R * G;
     KernelChoice k{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
-                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, false};
+                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, false};
     if constexpr (NP % 4 == 0 && NP <= 24) {
         k.zip2 = k_zpropagate2<NP / 4>;
         k.zip2_lds = &Zip2Geom<NP / 4>::lds_bytes;
@@ -307,9 +308,13 @@ template <int NT, int NSLAB>
 KernelChoice make_big()
 {
     constexpr int NP = 16 * NT;   // NT wavefronts per workgroup
+    // NT = 6, 10, 14: one tile-row per wavefront would load the SIMDs unevenly -> tiles dealt over 8 wavefronts
+    constexpr bool dealt = NT > 4 && NT % 4 != 0;
+    void (*prop)(BigArgs, const BigBlock *) = k_big_propagate<NT, NSLAB>;
+    if constexpr (dealt) prop = k_big_propagate_s<NT, NSLAB>;
     return KernelChoice{0, NT, NP, 0, 1, nullptr, nullptr, nullptr, k_chain<NP, 0>, false, k_big_table_raw<NT>,
-                        k_big_table_level<NT>, k_big_propagate<NT, NSLAB>, k_big_vector<NT>, BigVec<NT>::WAVES, NSLAB, BigSlab<NT, NSLAB>::bytes,
-                        nullptr, nullptr, false};
+                        k_big_table_level<NT>, prop, dealt ? BS_WAVES : NT, k_big_vector<NT>, BigVec<NT>::WAVES, NSLAB,
+                        BigSlab<NT, NSLAB>::bytes, nullptr, nullptr, false};
 }
 
 KernelChoice kChoices[] = {
@@ -979,7 +984,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                                             (int)LDS_BUDGET));
                 kc->zip_attr_set = true;
             }
-            hipLaunchKernelGGL(kc->big_prop, dim3((unsigned)gr.big_blocks.size(), (unsigned)B), dim3(kc->G * 64), kc->big_lds,
+            hipLaunchKernelGGL(kc->big_prop, dim3((unsigned)gr.big_blocks.size(), (unsigned)B), dim3(kc->big_prop_waves * 64), kc->big_lds,
                                stream, ba, (const BigBlock *)gr.d_big_blocks);
             note("k_big_propagate<" + std::to_string(kc->G) + ">" + strm);
             if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A); }

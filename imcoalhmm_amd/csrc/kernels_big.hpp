@@ -568,3 +568,197 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     if (tid == 0) a.EX[gv] = (int)ex;
 #undef BV_LOAD
 }
+
+// k_big_propagate with the output tiles of a step dealt round-robin over EIGHT wavefronts instead of one tile-row per
+// wavefront.  With NT = 6, 10 or 14 tile-rows the row-per-wavefront layout loads the four SIMDs unevenly (10
+// wavefronts = 3/3/2/2: the MFMA pipe of two SIMDs idles a third of the time); 8 wavefronts x (NT * TCS / 8) tiles
+// puts 13/13/12/12 tiles per step on the SIMDs at NT = 10.  Price: a wavefront's tiles no longer share a tile-row,
+// so the A fragment is read from the LDS panel once per tile instead of once per tile-row (1.5 LDS reads per MFMA
+// instead of 1.1) - still well inside the LDS bandwidth.  Everything else (slab resident in LDS, double-buffered
+// 16-deep A panels, one power-of-two scale per step) is k_big_propagate's.
+static constexpr int BS_WAVES = 8;
+
+template <int NT, int NSLAB>
+__global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, const BigBlock *blocks)
+{
+    using G = BigSlab<NT, NSLAB>;
+    constexpr int NP = G::NP, SC = G::SC, TCS = G::TCS, SPS = G::SPS, APS = G::APS, THREADS = BS_WAVES * 64;
+    // NT >= 8: wavefront w owns tile-row w (TCS tiles sharing one A fragment) plus its share of the rows beyond 8,
+    // dealt tile by tile; NT < 8: all tiles dealt round-robin
+    constexpr bool ROWS = NT >= BS_WAVES;
+    constexpr int NTILES = NT * TCS, NEXTRA = ROWS ? (NT - BS_WAVES) * TCS : NTILES;
+    constexpr int JROW = ROWS ? TCS : 0, JMAX = JROW + (NEXTRA + BS_WAVES - 1) / BS_WAVES;
+    constexpr int PANEL_D2 = NP * 8, EPT = (PANEL_D2 + THREADS - 1) / THREADS;   // double2 per panel, per thread
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *slab = lds;                              // [NP][SPS]  P[k][c - c0]
+    double *Apan = lds + G::SLAB_DOUBLES;            // [2][NP][APS]
+    __shared__ unsigned long long smax[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.y;
+    const BigBlock bk = blocks[blockIdx.x];
+    const SegDesc sd = a.segs[bk.seg];
+    const bool first = (sd.first & SEG_FIRST) != 0, wide = (sd.first & SEG_WIDE) != 0;
+    const int len = (int)sd.len;
+    const uint8_t *tokp = sd.obs;
+    const int c0 = (int)bk.slab * SC;                // first global column of this slab
+    const double *pp = a.params + (size_t)b * a.pstride;
+    const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
+    const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
+    const int *cex = a.cex + (size_t)b * a.A;
+
+    // initial slab: identity columns, or (first segment, slab 0) column 0 = pi .* E[:,o_0]
+    const int tok0 = first ? seg_token(tokp, wide, 0) : 0;
+    for (int idx = tid; idx < NP * SC; idx += THREADS) {
+        const int k = idx / SC, c = idx - k * SC;
+        double v;
+        if (first) v = (c0 + c == 0 && k < a.N) ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
+        else v = (k == c0 + c && k < a.N) ? 1.0 : 0.0;
+        slab[k * SPS + c] = v;
+    }
+    if (tid < 2) smax[tid] = 0ull;
+    __syncthreads();
+
+    // this wavefront's tiles: q = wave + 8 j  ->  (tile-row q / TCS, tile-column q % TCS)
+    int a_off[JMAX], b_off[JMAX], w_off[JMAX];
+    const int n_own = JROW + (NEXTRA - wave + BS_WAVES - 1) / BS_WAVES;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+        int tr, tc;
+        if (j < JROW) { tr = wave; tc = j; }
+        else {
+            const int x = wave + BS_WAVES * (j - JROW);
+            const int q = x < NEXTRA ? x : 0;                      // (unused slots repeat a valid tile)
+            tr = (ROWS ? BS_WAVES : 0) + q / TCS;
+            tc = q % TCS;
+        }
+        a_off[j] = (tr * 16 + lm) * APS + 4 * lg;          // A fragment in the LDS panel
+        b_off[j] = 4 * lg * SPS + tc * 16 + lm;            // B fragment in the slab (+ kb * 16 * SPS + s2 * SPS)
+        w_off[j] = (tr * 16 + lg) * SPS + tc * 16 + lm;    // D tile write-back (+ 4 q * SPS)
+    }
+    // A-panel staging: NP rows x 8 double2 per panel, EPT per thread (the last one guarded)
+    int lA[EPT];
+    size_t gAo[EPT];
+    bool act[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * THREADS;
+        act[k] = e < PANEL_D2;
+        const int ar = (act[k] ? e : 0) >> 3, ac = e & 7;
+        lA[k] = ar * APS + 2 * ac;
+        gAo[k] = (size_t)ar * NP + 2 * ac;
+    }
+    long long ex = 0;
+    int which = 0;
+    const int t_begin = first ? 1 : 0;
+    double2 sa[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) sa[k] = double2{0.0, 0.0};
+    if (t_begin < len) {
+        const double *A0 = Ct + (size_t)seg_token(tokp, wide, t_begin) * NP * NP;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+            if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(A0 + gAo[k]);
+    }
+    for (int t = t_begin; t < len; ++t) {
+        const int tok = seg_token(tokp, wide, t);
+        const double *A = Ct + (size_t)tok * NP * NP;
+        v4f64 acc[JMAX];
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) acc[j] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < EPT; ++k)
+            if (act[k]) *reinterpret_cast<double2 *>(Apan + lA[k]) = sa[k];
+        __syncthreads();
+#pragma unroll 1
+        for (int kb = 0; kb < NP / 16; ++kb) {
+            const int buf = kb & 1;
+            if (kb + 1 < NP / 16) {
+#pragma unroll
+                for (int k = 0; k < EPT; ++k)
+                    if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(A + gAo[k] + (kb + 1) * 16);
+            }
+            const double *Al = Apan + buf * G::A_DOUBLES;
+            const double *Bk = slab + (size_t)kb * 16 * SPS;
+            if constexpr (ROWS) {   // the wavefront's own tile-row: one A fragment for TCS tiles
+                const double2 *ap = reinterpret_cast<const double2 *>(Al + a_off[0]);
+                const double2 a01 = ap[0], a23 = ap[1];
+                const double av[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                    for (int j = 0; j < JROW; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[b_off[0] + s2 * SPS + j * 16], acc[j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = JROW; j < JMAX; ++j) {
+                if (j < n_own) {   // wave-uniform
+                    const double2 *ap = reinterpret_cast<const double2 *>(Al + a_off[j]);
+                    const double2 a01 = ap[0], a23 = ap[1];
+                    const double av[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+                        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[b_off[j] + s2 * SPS], acc[j], 0, 0, 0);
+                }
+            }
+            if (kb + 1 < NP / 16) {
+                double *An = Apan + (buf ^ 1) * G::A_DOUBLES;
+#pragma unroll
+                for (int k = 0; k < EPT; ++k)
+                    if (act[k]) *reinterpret_cast<double2 *>(An + lA[k]) = sa[k];
+            }
+            __syncthreads();
+        }
+        if (t + 1 < len) {   // prefetch the next token's first panel
+            const double *An = Ct + (size_t)seg_token(tokp, wide, t + 1) * NP * NP;
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(An + gAo[k]);
+        }
+        // one power-of-two scale for the slab: exponent of its largest entry
+        double mx = 0.0;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double v = (j < n_own) ? acc[j][q] : 0.0;
+                mx = (v > mx || v != v) ? v : mx;
+            }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double o = __shfl_xor(mx, m, 64);
+            mx = (o > mx || o != o) ? o : mx;
+        }
+        if (lane == 0) atomicMax(&smax[which], (unsigned long long)__double_as_longlong(mx));
+        __syncthreads();   // also: every wavefront has finished reading the slab
+        const double m = __longlong_as_double((long long)smax[which]);
+        if (tid == 0) smax[which ^ 1] = 0ull;
+        which ^= 1;
+        int e = 0;
+        (void)frexp(m, &e);
+        e = (m > 0.0 && m < INFINITY) ? e : 0;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j)
+            if (j < n_own) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) slab[w_off[j] + 4 * q * SPS] = ldexp(acc[j][q], -e);
+            }
+        ex += cex[tok] + e;
+        __syncthreads();
+    }
+    // results -> level 0: operator block state-major [i][c] (N x NP), or the vector [i] for a first segment
+    const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
+    double *Pout = a.P + gv * NP;
+    if (first) {
+        if (bk.slab == 0) {
+            for (int i = tid; i < a.N; i += THREADS) Pout[i] = slab[i * SPS];
+            if (tid == 0) a.EX[gv] = (int)ex;
+        }
+    } else {
+        for (int idx = tid; idx < a.N * SC; idx += THREADS) {
+            const int i = idx / SC, c = idx - i * SC;
+            if (c0 + c < NP) Pout[(size_t)i * NP + c0 + c] = (c0 + c < a.N) ? slab[i * SPS + c] : 0.0;
+        }
+        for (int c = tid; c < SC; c += THREADS)
+            if (c0 + c < a.N) a.EX[gv + c0 + c] = (int)ex;
+    }
+}
