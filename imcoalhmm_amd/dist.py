@@ -149,3 +149,61 @@ class SplitAlignmentLikelihood(object):
         if not self.model.valid_parameters(*parameters):
             return -float('inf')
         return self.forward_params(*self.model.build_hidden_markov_model(*parameters))
+
+
+class ProposalShardedLikelihood(object):
+    """The second sharding axis of SURVEY.md section 8e: when chunks are few (one long alignment) but proposals are
+    many, every rank holds ALL chunks and evaluates every ``world_size``-th parameter set; one ``all_gather`` of the
+    per-rank values gives every rank the whole batch.  ``local_eval(pis, Ts, Es) -> float64[b]`` may be injected
+    (CPU/gloo tests); by default it is ``forward_chunks_batch`` over this process's forwarders.
+    """
+
+    def __init__(self, model, forwarders, group=None, local_eval=None, gather_device=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.model = model
+        self.forwarders = list(forwarders) if hasattr(forwarders, '__iter__') else [forwarders]
+        self.group = group
+        self.gather_device = gather_device
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._local_eval = local_eval or (lambda pis, Ts, Es: hmm.forward_chunks_batch(
+            [f.handle for f in self.forwarders], pis, Ts, Es))
+
+    def forward_params_batch(self, pis, Ts, Es):
+        torch = self._torch
+        pis, Ts, Es = hmm._batch_params(pis, Ts, Es)
+        B = pis.shape[0]
+        mine = list(range(self.rank, B, self.world_size))
+        per_rank = (B + self.world_size - 1) // self.world_size
+        vals = np.zeros(per_rank, dtype=np.float64)                 # fixed-size record, padded with zeros
+        if mine:
+            vals[:len(mine)] = np.asarray(self._local_eval(pis[mine], Ts[mine], Es[mine]), dtype=np.float64)
+        t = torch.from_numpy(vals)
+        if self.gather_device is not None:
+            t = t.to(self.gather_device)
+        if self.world_size > 1:
+            parts = [torch.empty_like(t) for _ in range(self.world_size)]
+            self._dist.all_gather(parts, t, group=self.group)
+        else:
+            parts = [t]
+        out = np.empty(B, dtype=np.float64)
+        for r, part in enumerate(parts):
+            idx = list(range(r, B, self.world_size))
+            out[idx] = part.cpu().numpy()[:len(idx)]
+        return out
+
+    def batch(self, thetas):
+        thetas = [np.asarray(t, dtype=np.float64) for t in thetas]
+        out = np.full(len(thetas), -np.inf, dtype=np.float64)
+        valid = [k for k, t in enumerate(thetas) if self.model.valid_parameters(t)]
+        if valid:                       # every rank builds every HMM (cheap, deterministic) and evaluates its share
+            out[valid] = self.forward_params_batch(*build_hmms(self.model, [thetas[k] for k in valid]))
+        return out
+
+    def __call__(self, *parameters):
+        if not self.model.valid_parameters(*parameters):
+            return -float('inf')
+        pi, T, E = hmm._params(*self.model.build_hidden_markov_model(*parameters))
+        return float(self.forward_params_batch(pi[None], T[None], E[None])[0])

@@ -172,3 +172,50 @@ def test_split_alignment_world(world):
         assert got[2] == -float("inf")
         assert abs(batch[0] - want[0]) / abs(want[0]) < 1e-12 and abs(batch[1] - want[1]) / abs(want[1]) < 1e-12
     assert all(r[2][:2] == res[0][2][:2] for r in res)                     # identical on all ranks
+
+
+def _proposal_worker(rank, world, port, q):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from imcoalhmm_amd import models, synth
+    from imcoalhmm_amd.dist import ProposalShardedLikelihood
+    from oracle import oracle_lib
+    model = models.IsolationModel(6)
+    theta0 = np.array([0.001, 1000.0, 0.4])
+    chunks = [synth.sample_alignment(*model.build_hidden_markov_model(theta0), 1500 + 200 * k, seed=900 + k) for k in range(2)]
+    calls = []
+
+    def local_eval(pis, Ts, Es):
+        calls.append(pis.shape[0])
+        return np.array([sum(oracle_lib.forward_scaled(pis[b], Ts[b], Es[b], c) for c in chunks) for b in range(pis.shape[0])])
+
+    ll = ProposalShardedLikelihood(model, [object(), object()], local_eval=local_eval)
+    thetas = [theta0 * (1 + 0.05 * k) for k in range(5)] + [-theta0]
+    got = ll.batch(thetas)
+    want = [sum(oracle_lib.forward_scaled(*model.build_hidden_markov_model(t), c) for c in chunks) for t in thetas[:5]]
+    q.put((rank, got.tolist(), want, calls, ll(theta0)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_proposal_sharding_world2():
+    """Few chunks, many proposals: ranks split the parameter sets (second axis) and all_gather the values."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_proposal_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, want, calls, single in res:
+        assert all(abs(g - w) / abs(w) < 1e-13 for g, w in zip(got[:5], want))
+        assert got[5] == -float("inf")
+        assert abs(single - want[0]) / abs(want[0]) < 1e-13
+    assert sorted(r[3][0] for r in res) == [2, 3]          # 5 valid proposals split 3 + 2
+    assert res[0][1] == res[1][1]
