@@ -1,6 +1,8 @@
 """Seeded randomized sweep over the whole dispatch space: N, alphabet, chunk mixes (empty / tiny / long,
 compressible or not), stream + kernel modes, forced segment lengths and batch sizes - every value checked
 against the CPU oracle.  Catches dispatch/planning bugs that the per-kernel tests cannot."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,7 @@ from imcoalhmm_amd import Forwarder, _capi, synth
 from imcoalhmm_amd.hmm import forward_chunks_batch
 
 pytestmark = pytest.mark.gpu
+N_CASES = int(os.environ.get("IMC_FUZZ_CASES", "150"))     # soak runs: IMC_FUZZ_CASES=1500
 
 
 def _chunk(rng, nsym, L):
@@ -20,7 +23,7 @@ def _chunk(rng, nsym, L):
     return rng.integers(0, nsym, size=L).astype(np.uint8)
 
 
-@pytest.mark.parametrize("case", range(150))
+@pytest.mark.parametrize("case", range(N_CASES))
 def test_random_dispatch(oracle, case):
     rng = np.random.default_rng(1000 + case)
     L = _capi.lib()
@@ -52,7 +55,7 @@ def test_random_dispatch(oracle, case):
             assert (g == 0.0 and want == 0.0) or rel_err(g, want) < 1e-11, (case, n, nsym, mode, seg, B, lens, kernels, b, f, g, want)
 
 
-@pytest.mark.parametrize("case", range(40))
+@pytest.mark.parametrize("case", range(max(40, N_CASES // 4)))
 def test_random_split_state(oracle, case):
     """imc_forward_state under the same random dispatch: a random alignment cut at random points, vector from the
     first piece and operators from the rest, recombined and checked against the oracle on the whole alignment."""
