@@ -986,7 +986,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             }
             hipLaunchKernelGGL(kc->big_prop, dim3((unsigned)gr.big_blocks.size(), (unsigned)B), dim3(kc->big_prop_waves * 64), kc->big_lds,
                                stream, ba, (const BigBlock *)gr.d_big_blocks);
-            note("k_big_propagate<" + std::to_string(kc->G) + ">" + strm);
+            note(std::string(kc->big_prop_waves != kc->G ? "k_big_propagate_s<" : "k_big_propagate<") + std::to_string(kc->G) + ">" + strm);
             if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A); }
             else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }
         } else if (gr.zip2) {
