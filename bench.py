@@ -180,6 +180,11 @@ def main():
     lib.imc_profile_read(ctypes.byref(ms_p), ctypes.byref(ms_s), ctypes.byref(n_p), ctypes.byref(n_s))
     lib.imc_profile_enable(0)
     plan = _capi.last_plan()
+    rank1_stats = None
+    if world == 1 and args.batch == 1:     # one extra synchronous evaluation: the hand-off counters are read back there
+        from imcoalhmm_amd.hmm import forward_chunks
+        forward_chunks([f.handle for f in forwarders], pi, T, E)
+        rank1_stats = dict(zip(("segments_tested", "collapsed"), _capi.last_rank1()))
     ntok0, alpha0 = forwarders[0].compressed_length(plan["token_alphabet"] or 256) if plan["vector_tokens"] else (len(forwarders[0]), 3)
 
     if world > 1:
@@ -242,7 +247,8 @@ def main():
                        "column_segment_len": plan["column_segment_len"], "token_segment_len": plan["token_segment_len"],
                        "compression": "pair dictionary, %d tokens" % plan["token_alphabet"] if plan["vector_tokens"] else "off",
                        "columns_per_token": (len(forwarders[0]) / max(ntok0, 1)) if plan["vector_tokens"] else 1.0,
-                       "setup_s": t_setup, "model_build_ms_per_hmm": model_build_ms, "loglik": value},
+                       "setup_s": t_setup, "model_build_ms_per_hmm": model_build_ms, "loglik": value,
+                       "rank1_handoff": rank1_stats},
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,

@@ -59,6 +59,7 @@ SIGNATURES = [
     ("imc_dictionary_reset", ctypes.c_int, []),
     ("imc_profile_enable", ctypes.c_int, [ctypes.c_int]),
     ("imc_profile_read", ctypes.c_int, [_dp, _dp, _u64p, _u64p]),
+    ("imc_last_rank1", ctypes.c_int, [_u64p, _u64p]),
     ("imc_last_plan", ctypes.c_int, [_u64p]),
     ("imc_last_kernels", ctypes.c_char_p, []),
 ]
@@ -118,6 +119,13 @@ def handle_array(handles):
     for i, h in enumerate(handles):
         arr[i] = h
     return arr
+
+
+def last_rank1():
+    """(operator segments tested, certified rank one) by the GEMM chain's rank-one hand-off in the last call."""
+    a, b = ctypes.c_uint64(), ctypes.c_uint64()
+    check(lib().imc_last_rank1(ctypes.byref(a), ctypes.byref(b)))
+    return int(a.value), int(b.value)
 
 
 def last_plan():

@@ -71,6 +71,9 @@ constexpr size_t DICT_TRAIN_MAX = 8u << 20;        // byte tokens (< 256): train
 constexpr size_t DICT_WIDE_TRAIN_TOKENS = 1u << 19; // 16-bit tokens: train on at most this many byte-level tokens (~4e7 columns)
 constexpr size_t DICT_WIDE_MIN_COUNT = 6;          // ... in which a pair must occur this often
 constexpr size_t CTAB_BUDGET = (size_t)24 << 30;   // largest operator table (all parameter sets) a plan may allocate
+constexpr size_t R1_MIN_SEGLEN = 1024;             // rank-one hand-off: segments at least this long (stream elements) ...
+constexpr size_t R1_MIN_HEAD = 256;                // ... run at least this many on the GEMM chain before the test
+constexpr double R1_HEAD_COLUMNS = 65536.0;        // ... and about this many alignment columns
 
 struct DictDev {                                   // one trained dictionary + its device copy
     imc::PairDict dict;
@@ -98,11 +101,13 @@ struct Ctx {
     int compression = 1;      // 0 = raw symbol stream, 1 = pair-compressed token stream where possible
     int kernel_pref = 0;      // 0 = automatic, 1 = vector kernels (k_propagate / k_zpropagate), 2 = blocked (k_zpropagate2)
     bool profile = false;
+    bool rank1_handoff = true; // IMC_RANK1=0 switches the rank-one hand-off of the GEMM chain off (A/B measurements)
     bool use_graphs = false;  // IMC_GRAPH=1: replay each plan's launch sequence as a hipGraph (measured: no gain, the
                               // per-evaluation latency is kernel time + kernel boundaries, not host launch cost)
     std::vector<Ev3> events;
     std::map<int, std::shared_ptr<DictDev>> dicts;   // by raw alphabet size
     uint64_t last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t r1_checked = 0, r1_collapsed = 0;   // last call: operator segments tested / certified rank one
     std::string last_kernels;   // propagate kernels of the last enqueue, e.g. "k_zpropagate2<5>[tokens]"
 } g;
 
@@ -137,6 +142,7 @@ int ensure_ctx()
     g.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     g.use_graphs = std::getenv("IMC_GRAPH") != nullptr;
+    if (const char *r1 = std::getenv("IMC_RANK1")) g.rank1_handoff = std::atoi(r1) != 0;
     g.pid = me;
     g.ready = true;
     return IMC_OK;
@@ -282,6 +288,7 @@ struct KernelChoice {
     void (*big_prop)(BigArgs, const BigBlock *);
     int big_prop_waves;            // wavefronts per workgroup of big_prop (NT, or 8 for the dealt-tiles variant)
     void (*big_vec)(BigArgs, const BigBlock *, int, int);
+    void (*big_vec_tail)(BigArgs, const BigBlock *, int, int);   // rank-one hand-off: mat-vec chain over segment tails
     int big_vec_waves;
     int big_nslab;
     size_t big_lds;
@@ -296,7 +303,7 @@ KernelChoice make_kc()
 {
     constexpr int NP = R * G;
     KernelChoice k{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
-                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, false};
+                   k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, false};
     if constexpr (NP % 4 == 0 && NP <= 24) {
         k.zip2 = k_zpropagate2<NP / 4>;
         k.zip2_lds = &Zip2Geom<NP / 4>::lds_bytes;
@@ -313,7 +320,7 @@ KernelChoice make_big()
     void (*prop)(BigArgs, const BigBlock *) = k_big_propagate<NT, NSLAB>;
     if constexpr (dealt) prop = k_big_propagate_s<NT, NSLAB>;
     return KernelChoice{0, NT, NP, 0, 1, nullptr, nullptr, nullptr, k_chain<NP, 0>, false, k_big_table_raw<NT>,
-                        k_big_table_level<NT>, prop, dealt ? BS_WAVES : NT, k_big_vector<NT>, BigVec<NT>::WAVES, NSLAB,
+                        k_big_table_level<NT>, prop, dealt ? BS_WAVES : NT, k_big_vector<NT, false>, k_big_vector<NT, true>, BigVec<NT>::WAVES, NSLAB,
                         BigSlab<NT, NSLAB>::bytes, nullptr, nullptr, false};
 }
 
@@ -359,6 +366,15 @@ struct Group {             // one propagate launch
     Z2Block *d_blocks = nullptr;
     double *d_Ctab = nullptr;
     int *d_cex = nullptr;
+    // rank-one hand-off (GEMM chain only): operator segments run head_len tokens on the GEMM chain, are tested by
+    // k_rank1_check, and those that collapsed to u alpha^T finish on the mat-vec chain
+    bool rank1 = false;
+    int head_len = 0;
+    std::vector<BigBlock> tail_blocks;        // one entry per segment (operator tails and first segments)
+    std::vector<uint32_t> r1_eligible;        // plan-wide ids of the operator segments longer than head_len
+    BigBlock *d_tail_blocks = nullptr;
+    int *d_r1flag = nullptr;
+    double *d_r1u = nullptr, *d_r1alpha = nullptr;
     bool zip = false;
     int level = -1, A = 0;
     std::shared_ptr<DictDev> dict;
@@ -407,7 +423,7 @@ struct Plan {
         if (graph) (void)hipGraphExecDestroy(graph);
         (void)hipFree(d_segs); (void)hipFree(d_vecs); (void)hipFree(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_seg_out); (void)hipFree(gr.d_blocks); (void)hipFree(gr.d_big_blocks); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_cex); }
+        for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_seg_out); (void)hipFree(gr.d_blocks); (void)hipFree(gr.d_big_blocks); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_cex); (void)hipFree(gr.d_tail_blocks); (void)hipFree(gr.d_r1flag); (void)hipFree(gr.d_r1u); (void)hipFree(gr.d_r1alpha); }
         (void)hipFree(d_params); (void)hipFree(d_out);
         (void)hipHostFree(h_params); (void)hipHostFree(h_out);
     }
@@ -644,6 +660,41 @@ struct PlanBuilder {
             if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);   // tests: force stitching
             if (gr.bigvec)
                 for (size_t L : lens) gr.bigvec = gr.bigvec && L <= gr.seglen && !op_mode;
+            // rank-one hand-off: worth a test once segments are much longer than the HMM's memory (tens of thousands
+            // of columns); a quarter of the segment on the GEMM chain, then the certified test
+            if (gr.big && !gr.bigvec && g.rank1_handoff && gr.seglen >= R1_MIN_SEGLEN) {
+                // head: ~R1_HEAD_COLUMNS alignment columns on the GEMM chain (the HMM's memory is a property of the
+                // model, not of the segmentation).  The tails then cost a mat-vec per step, so MORE, shorter
+                // segments pay: m times the segments = m rounds of heads, tails 1/m as long.  Pick m by the model;
+                // if the test fails at run time the GEMM chain does the same total work as with m = 1.
+                double cols = 0.0, toks = 0.0;
+                for (int f : gr.chunks) { cols += (double)chunks[f]->L; toks += (double)(gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L); }
+                const double span = toks > 0.0 ? cols / toks : 1.0;
+                const size_t head = round_up(std::max<size_t>(R1_MIN_HEAD, (size_t)(R1_HEAD_COLUMNS / span)), 16);
+                const double np2 = (double)kc->NP * kc->NP, t_gemm = 0.027 * np2 * kc->NP + 20000.0;
+                const double table_mb = (double)gr.A * np2 * 8.0 / 1.0e6;
+                // a lone chain streams its operators at ~11 GB/s from HBM (measured, 1.6 GB table), faster from the caches
+                const double t_vec = table_mb > 128.0 ? np2 * 1.5 : matvec_step_cycles(np2, gr.A);
+                const double nseg = std::max(1.0, toks / (double)gr.seglen);
+                if (g.seg_override) {
+                    if (gr.seglen >= 4 * R1_MIN_HEAD) { gr.rank1 = true; gr.head_len = (int)round_up(gr.seglen / 4, 16); }
+                } else {
+                    double best = 1e300;
+                    int best_m = 0;
+                    for (int m = 1; m <= 6; ++m) {
+                        const double sl = (double)gr.seglen / m;
+                        if (sl < 2.0 * head) break;
+                        const double share = std::max(1.0, m * nseg / (double)g.cus);
+                        const double est = m * (double)head * t_gemm + (sl - head) * t_vec * share;
+                        if (est < best) { best = est; best_m = m; }
+                    }
+                    if (best_m) {
+                        gr.rank1 = true;
+                        gr.head_len = (int)head;
+                        gr.seglen = std::max<size_t>(16, round_up(gr.seglen / best_m, 16));
+                    }
+                }
+            }
         }
     }
 
@@ -819,6 +870,18 @@ struct PlanBuilder {
             e = up((void **)&gr.d_big_blocks, gr.big_blocks.data(), gr.big_blocks.size() * sizeof(BigBlock));
             if (e == hipSuccess) e = hipMalloc((void **)&gr.d_Ctab, (size_t)B * gr.A * np2 * 8);
             if (e == hipSuccess) e = hipMalloc((void **)&gr.d_cex, (size_t)B * gr.A * 4 + 16);
+            if (gr.rank1) {
+                for (size_t i2 = 0; i2 < gr.seg_ids.size(); ++i2)
+                {
+                    gr.tail_blocks.push_back(BigBlock{gr.seg_ids[i2], 0u, gr.seg_out[i2], 0u});   // (first segments included)
+                    if (!seg_first[gr.seg_ids[i2]] && (int)segs[gr.seg_ids[i2]].len > gr.head_len) gr.r1_eligible.push_back(gr.seg_ids[i2]);
+                }
+                const size_t nrec = (size_t)B * segs.size();
+                if (e == hipSuccess) e = up((void **)&gr.d_tail_blocks, gr.tail_blocks.data(), gr.tail_blocks.size() * sizeof(BigBlock));
+                if (e == hipSuccess) e = zalloc((void **)&gr.d_r1flag, nrec * 4);
+                if (e == hipSuccess) e = hipMalloc((void **)&gr.d_r1u, std::max<size_t>(nrec * kc->NP * 8, 16));
+                if (e == hipSuccess) e = hipMalloc((void **)&gr.d_r1alpha, std::max<size_t>(nrec * kc->NP * 8, 16));
+            }
         }
         if (e == hipSuccess) e = hipMalloc((void **)&q->d_params, (size_t)B * q->pstride * 8);
         if (e == hipSuccess) e = hipMalloc((void **)&q->d_out, (size_t)B * std::max(n_chunks, 1) * 8);
@@ -945,6 +1008,8 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
             ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
+            ba.phase = gr.rank1 ? 1 : 0; ba.head_len = gr.head_len; ba.r1flag = gr.d_r1flag; ba.r1u = gr.d_r1u;
+            ba.r1alpha = gr.d_r1alpha; ba.n_segs = p->n_segs;
             hipLaunchKernelGGL(kc->big_table_raw, dim3((unsigned)S, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
             if (gr.zip) {   // merged tokens, one launch per dictionary depth (tokens of a depth are independent)
@@ -970,7 +1035,8 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                 }
             }
             if (gr.bigvec) {
-                const unsigned grid = 8u * (unsigned)gr.big_blocks.size() * (unsigned)((B + 7) / 8);
+                const unsigned grid = B >= 8 ? 8u * (unsigned)gr.big_blocks.size() * (unsigned)((B + 7) / 8)
+                                             : (unsigned)gr.big_blocks.size() * (unsigned)B;
                 hipLaunchKernelGGL(kc->big_vec, dim3(grid), dim3(kc->big_vec_waves * 64), 0, stream, ba,
                                    (const BigBlock *)gr.d_big_blocks, (int)gr.big_blocks.size(), B);
                 note("k_big_vector<" + std::to_string(kc->G) + ">" + strm);
@@ -987,6 +1053,24 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             hipLaunchKernelGGL(kc->big_prop, dim3((unsigned)gr.big_blocks.size(), (unsigned)B), dim3(kc->big_prop_waves * 64), kc->big_lds,
                                stream, ba, (const BigBlock *)gr.d_big_blocks);
             note(std::string(kc->big_prop_waves != kc->G ? "k_big_propagate_s<" : "k_big_propagate<") + std::to_string(kc->G) + ">" + strm);
+            if (gr.rank1 && !gr.tail_blocks.empty()) {
+                // heads are done: certify which operators collapsed to rank one, finish those on the mat-vec chain and
+                // the others on the GEMM chain (both launches cover all tails; a workgroup whose segment belongs to
+                // the other kernel exits at once, so no host round trip is needed)
+                HIP_TRY(hipGetLastError());
+                hipLaunchKernelGGL(k_rank1_check, dim3((unsigned)gr.tail_blocks.size(), (unsigned)B), dim3(256), 0, stream, ba,
+                                   (const BigBlock *)gr.d_tail_blocks, NP);
+                HIP_TRY(hipGetLastError());
+                const unsigned grid = B >= 8 ? 8u * (unsigned)gr.tail_blocks.size() * (unsigned)((B + 7) / 8)
+                                             : (unsigned)gr.tail_blocks.size() * (unsigned)B;
+                hipLaunchKernelGGL(kc->big_vec_tail, dim3(grid), dim3(kc->big_vec_waves * 64), 0, stream, ba,
+                                   (const BigBlock *)gr.d_tail_blocks, (int)gr.tail_blocks.size(), B);
+                HIP_TRY(hipGetLastError());
+                ba.phase = 2;
+                hipLaunchKernelGGL(kc->big_prop, dim3((unsigned)gr.big_blocks.size(), (unsigned)B), dim3(kc->big_prop_waves * 64), kc->big_lds,
+                                   stream, ba, (const BigBlock *)gr.d_big_blocks);
+                note("rank1-handoff");
+            }
             if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A); }
             else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }
         } else if (gr.zip2) {
@@ -1061,6 +1145,22 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
     return IMC_OK;
 }
 
+// After a call has been synchronised: how many operator segments the rank-one test saw and how many it certified.
+void collect_rank1_stats(Plan *p)
+{
+    g.r1_checked = g.r1_collapsed = 0;
+    for (const Group &gr : p->groups) {
+        if (!gr.rank1 || gr.r1_eligible.empty()) continue;
+        std::vector<int> flags((size_t)p->B * p->n_segs);
+        if (hipMemcpy(flags.data(), gr.d_r1flag, flags.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) continue;
+        for (int b = 0; b < p->B; ++b)
+            for (uint32_t sid : gr.r1_eligible) {
+                ++g.r1_checked;
+                g.r1_collapsed += flags[(size_t)b * p->n_segs + sid] ? 1 : 0;
+            }
+    }
+}
+
 int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, const double *pis, const double *Ts,
               const double *Es, double *out_sum, double *out_per_chunk)
 {
@@ -1091,6 +1191,7 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
     for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
     g.last_kernels = p->kernels;
     HIP_TRY(hipStreamSynchronize(g.stream));
+    collect_rank1_stats(p);
     for (int b = 0; b < B; ++b) {
         double tot = 0.0;   // Python sum(): left to right from 0 (likelihood.py:33)
         for (int f = 0; f < n_chunks; ++f) {
@@ -1384,6 +1485,14 @@ const char *imc_last_kernels(void)
     static thread_local std::string copy;
     copy = g.last_kernels;
     return copy.c_str();
+}
+
+int imc_last_rank1(uint64_t *checked, uint64_t *collapsed)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (checked) *checked = g.r1_checked;
+    if (collapsed) *collapsed = g.r1_collapsed;
+    return IMC_OK;
 }
 
 int imc_last_plan(uint64_t *out8)

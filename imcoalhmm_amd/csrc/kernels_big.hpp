@@ -37,6 +37,13 @@ struct BigArgs {
     int *cex;                     // [B][A] power-of-two exponents of the table entries
     double *P;                    // level-0 results (see kernels_stitch.hpp for the layout)
     int *EX;
+    // rank-one hand-off (see k_rank1_check): 0 = whole segments; 1 = heads only (operator segments stop after
+    // head_len tokens); 2 = tails of the segments that did NOT collapse, continued from their stored block
+    int phase;
+    int head_len;
+    int *r1flag;                  // [B][n_segs] 1: the head operator is rank one within R1_TOL
+    double *r1u, *r1alpha;        // [B][n_segs][NP] its column direction u and column scales alpha
+    uint32_t n_segs;
 };
 
 
@@ -313,12 +320,20 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
     const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
     const int *cex = a.cex + (size_t)b * a.A;
 
-    // initial slab: identity columns, or (first segment, slab 0) column 0 = pi .* E[:,o_0]
+    // phases of the rank-one hand-off: which tokens this launch covers
+    const bool tail = a.phase == 2;
+    if (a.phase != 0 && first) return;             // hand-off mode: first segments run on the mat-vec chain kernel
+    if (tail && (len <= a.head_len || a.r1flag[(size_t)b * a.n_segs + bk.seg])) return;   // nothing left for the GEMM chain
+    const int t_end = (a.phase == 1 && !first && len > a.head_len) ? a.head_len : len;
+    const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
+    double *Pout = a.P + gv * NP;
+    // initial slab: identity columns, or (first segment, slab 0) column 0 = pi .* E[:,o_0], or (tail) the stored block
     const int tok0 = first ? seg_token(tokp, wide, 0) : 0;
     for (int idx = tid; idx < NP * SC; idx += THREADS) {
         const int k = idx / SC, c = idx - k * SC;
         double v;
-        if (first) v = (c0 + c == 0 && k < a.N) ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
+        if (tail) v = (k < a.N && c0 + c < NP) ? Pout[(size_t)k * NP + c0 + c] : 0.0;
+        else if (first) v = (c0 + c == 0 && k < a.N) ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
         else v = (k == c0 + c && k < a.N) ? 1.0 : 0.0;
         slab[k * SPS + c] = v;
     }
@@ -330,19 +345,19 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
     const int ar0 = e0 >> 3, ac0 = e0 & 7, ar1 = e1 >> 3, ac1 = e1 & 7;
     const int lA0 = ar0 * APS + 2 * ac0, lA1 = ar1 * APS + 2 * ac1;
     const int row0 = wave * 16;
-    long long ex = 0;
+    long long ex = tail ? (long long)a.EX[gv + (c0 < a.N ? c0 : 0)] : 0;
     int which = 0;
     // the first A panel of the NEXT token is fetched while the current step finishes (exponent, write-back),
     // so no step starts with an exposed L2 round trip
-    const int t_begin = first ? 1 : 0;
+    const int t_begin = tail ? a.head_len : first ? 1 : 0;
     const size_t aoff0 = (size_t)ar0 * NP + 2 * ac0, aoff1 = (size_t)ar1 * NP + 2 * ac1;
     double2 sa0 = double2{0.0, 0.0}, sa1 = double2{0.0, 0.0};
-    if (t_begin < len) {
+    if (t_begin < t_end) {
         const double *A0 = Ct + (size_t)seg_token(tokp, wide, t_begin) * NP * NP;
         sa0 = *reinterpret_cast<const double2 *>(A0 + aoff0);
         sa1 = *reinterpret_cast<const double2 *>(A0 + aoff1);
     }
-    for (int t = t_begin; t < len; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         const int tok = seg_token(tokp, wide, t);
         const double *A = Ct + (size_t)tok * NP * NP;
         const double *gA0 = A + aoff0, *gA1 = A + aoff1;
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
             }
             __syncthreads();
         }
-        if (t + 1 < len) {   // prefetch the next token's first panel
+        if (t + 1 < t_end) {   // prefetch the next token's first panel
             const double *An = Ct + (size_t)seg_token(tokp, wide, t + 1) * NP * NP;
             sa0 = *reinterpret_cast<const double2 *>(An + aoff0);
             sa1 = *reinterpret_cast<const double2 *>(An + aoff1);
@@ -411,8 +426,6 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
         __syncthreads();
     }
     // results -> level 0: operator block state-major [i][c] (N x NP), or the vector [i] for a first segment
-    const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
-    double *Pout = a.P + gv * NP;
     if (first) {
         if (bk.slab == 0) {
             for (int i = tid; i < a.N; i += THREADS) Pout[i] = slab[i * SPS];
@@ -448,7 +461,9 @@ struct BigVec {
     static constexpr bool LOAD_AHEAD = !PIPELINED && NT <= 12;
 };
 
-template <int NT>
+// TAIL = true is the second half of the rank-one hand-off (k_rank1_check): the chain starts from the collapsed
+// operator's column direction u after head_len tokens and ends by writing the operator block u' alpha^T.
+template <int NT, bool TAIL = false>
 __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a, const BigBlock *blocks, int n_blocks, int B)
 {
     constexpr int BV_WAVES = BigVec<NT>::WAVES;
@@ -458,10 +473,19 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     constexpr int W = NT % 2 == 0 ? 2 : 1, NJ = NT / W;   // lane lm takes k = W lm + 16 W jj + (0..W-1): 16-byte loads when NT is even
     __shared__ __attribute__((aligned(16))) double xs[2][NP];
     __shared__ unsigned long long smax[3];
-    const int xcd = blockIdx.x & 7, turn = blockIdx.x >> 3;
-    const int b = xcd + 8 * (turn / n_blocks);
-    if (b >= B) return;
-    const BigBlock bk = blocks[turn % n_blocks];
+    // B >= 8: all chains of one parameter set on one XCD (they share its table in that L2); fewer sets: spread the
+    // chains over every XCD (grid = n_blocks * B, consecutive ids go round the XCDs)
+    int b, blk;
+    if (B >= 8) {
+        const int xcd = blockIdx.x & 7, turn = blockIdx.x >> 3;
+        b = xcd + 8 * (turn / n_blocks);
+        blk = turn % n_blocks;
+    } else {
+        b = blockIdx.x % B;
+        blk = blockIdx.x / B;
+    }
+    if (b >= B || blk >= n_blocks) return;
+    const BigBlock bk = blocks[blk];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lm = lane & 15, lg = lane >> 4;
     const SegDesc sd = a.segs[bk.seg];
     const int len = (int)sd.len;
@@ -472,8 +496,18 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
     const int *cex = a.cex + (size_t)b * a.A;
 
-    const int tok0 = seg_token(tokp, wide, 0);
-    for (int k = tid; k < NP; k += THREADS) xs[0][k] = k < a.N ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
+    const size_t r1 = ((size_t)b * a.n_segs + bk.seg) * NP;
+    // TAIL launches cover every segment of the hand-off group: a chunk's first segment is a plain vector chain from
+    // pi, an operator segment continues from u if (and only if) its head was certified rank one
+    const bool from_u = TAIL && !(sd.first & SEG_FIRST);
+    if (from_u) {
+        if (len <= a.head_len || !a.r1flag[(size_t)b * a.n_segs + bk.seg]) return;
+        for (int k = tid; k < NP; k += THREADS) xs[0][k] = k < a.N ? a.r1u[r1 + k] : 0.0;
+    } else {
+        const int tok0 = seg_token(tokp, wide, 0);
+        for (int k = tid; k < NP; k += THREADS) xs[0][k] = k < a.N ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
+    }
+    const int t0 = from_u ? a.head_len : 1;        // first token applied as an operator
     if (tid < 3) smax[tid] = 0ull;
     __syncthreads();
 
@@ -501,14 +535,14 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
             }                                                                                       \
         }                                                                                           \
     } while (0)
-    int tok = len > 1 ? seg_token(tokp, wide, 1) : 0;
-    int tok_next = len > 2 ? seg_token(tokp, wide, 2) : tok;
+    int tok = len > t0 ? seg_token(tokp, wide, t0) : 0;
+    int tok_next = len > t0 + 1 ? seg_token(tokp, wide, t0 + 1) : tok;
     if constexpr (BigVec<NT>::PIPELINED) {
         const double *A = Ct + (size_t)tok * NP * NP;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) BV_LOAD(ps, A);
     }
-    for (int t = 1; t < len; ++t) {
+    for (int t = t0; t < len; ++t) {
         const double *An = Ct + (size_t)(BigVec<NT>::PIPELINED ? tok_next : tok) * NP * NP;
         if constexpr (BigVec<NT>::LOAD_AHEAD) {
 #pragma unroll
@@ -564,8 +598,16 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     }
     const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
     double *Pout = a.P + gv * NP;
-    for (int i = tid; i < a.N; i += THREADS) Pout[i] = ldexp(xs[cur][i], -e_prev);
-    if (tid == 0) a.EX[gv] = (int)ex;
+    if (from_u) {   // the operator block u' alpha^T, state-major [i][c]; column exponents grow by the tail's
+        for (int idx = tid; idx < a.N * NP; idx += THREADS) {
+            const int i = idx / NP, c = idx - i * NP;
+            Pout[idx] = c < a.N ? ldexp(xs[cur][i], -e_prev) * a.r1alpha[r1 + c] : 0.0;
+        }
+        for (int c = tid; c < a.N; c += THREADS) a.EX[gv + c] += (int)ex;
+    } else {
+        for (int i = tid; i < a.N; i += THREADS) Pout[i] = ldexp(xs[cur][i], -e_prev);
+        if (tid == 0) a.EX[gv] = (int)ex;
+    }
 #undef BV_LOAD
 }
 
@@ -606,12 +648,20 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
     const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
     const int *cex = a.cex + (size_t)b * a.A;
 
-    // initial slab: identity columns, or (first segment, slab 0) column 0 = pi .* E[:,o_0]
+    // phases of the rank-one hand-off: which tokens this launch covers
+    const bool tail = a.phase == 2;
+    if (a.phase != 0 && first) return;             // hand-off mode: first segments run on the mat-vec chain kernel
+    if (tail && (len <= a.head_len || a.r1flag[(size_t)b * a.n_segs + bk.seg])) return;   // nothing left for the GEMM chain
+    const int t_end = (a.phase == 1 && !first && len > a.head_len) ? a.head_len : len;
+    const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
+    double *Pout = a.P + gv * NP;
+    // initial slab: identity columns, or (first segment, slab 0) column 0 = pi .* E[:,o_0], or (tail) the stored block
     const int tok0 = first ? seg_token(tokp, wide, 0) : 0;
     for (int idx = tid; idx < NP * SC; idx += THREADS) {
         const int k = idx / SC, c = idx - k * SC;
         double v;
-        if (first) v = (c0 + c == 0 && k < a.N) ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
+        if (tail) v = (k < a.N && c0 + c < NP) ? Pout[(size_t)k * NP + c0 + c] : 0.0;
+        else if (first) v = (c0 + c == 0 && k < a.N) ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
         else v = (k == c0 + c && k < a.N) ? 1.0 : 0.0;
         slab[k * SPS + c] = v;
     }
@@ -647,19 +697,19 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
         lA[k] = ar * APS + 2 * ac;
         gAo[k] = (size_t)ar * NP + 2 * ac;
     }
-    long long ex = 0;
+    long long ex = tail ? (long long)a.EX[gv + (c0 < a.N ? c0 : 0)] : 0;
     int which = 0;
-    const int t_begin = first ? 1 : 0;
+    const int t_begin = tail ? a.head_len : first ? 1 : 0;
     double2 sa[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) sa[k] = double2{0.0, 0.0};
-    if (t_begin < len) {
+    if (t_begin < t_end) {
         const double *A0 = Ct + (size_t)seg_token(tokp, wide, t_begin) * NP * NP;
 #pragma unroll
         for (int k = 0; k < EPT; ++k)
             if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(A0 + gAo[k]);
     }
-    for (int t = t_begin; t < len; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         const int tok = seg_token(tokp, wide, t);
         const double *A = Ct + (size_t)tok * NP * NP;
         v4f64 acc[JMAX];
@@ -708,7 +758,7 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
             }
             __syncthreads();
         }
-        if (t + 1 < len) {   // prefetch the next token's first panel
+        if (t + 1 < t_end) {   // prefetch the next token's first panel
             const double *An = Ct + (size_t)seg_token(tokp, wide, t + 1) * NP * NP;
 #pragma unroll
             for (int k = 0; k < EPT; ++k)
@@ -746,8 +796,6 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
         __syncthreads();
     }
     // results -> level 0: operator block state-major [i][c] (N x NP), or the vector [i] for a first segment
-    const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
-    double *Pout = a.P + gv * NP;
     if (first) {
         if (bk.slab == 0) {
             for (int i = tid; i < a.N; i += THREADS) Pout[i] = slab[i * SPS];
@@ -761,4 +809,67 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
         for (int c = tid; c < SC; c += THREADS)
             if (c0 + c < a.N) a.EX[gv + c0 + c] = (int)ex;
     }
+}
+
+// Rank-one hand-off.  A product of many positive operators forgets its input: after enough columns every column of a
+// segment's transfer operator P points in the same direction (Birkhoff contraction), P = u alpha^T, and the rest of
+// the segment only has to propagate the VECTOR u - N^2 instead of N^3 work per step.  The hand-off is certified,
+// not assumed: after head_len tokens this kernel tests, component-wise,
+//     | P[i][c] s_* / (P[i][c*] s_c) - 1 | <= R1_TOL      for every i, c   (s_c = column sums, c* = the largest column)
+// and only then records u = P[:, c*], alpha_c = s_c / s_*.  A component-wise relative bound survives every later
+// non-negative linear map unchanged, so the log-likelihood moves by at most R1_TOL (2^-42 = 2.3e-13) per collapsed
+// segment - absolute, in nats, on segments whose own log-likelihood is in the thousands.  Segments that fail the
+// test (slow mixing, structural zeros) simply continue on the GEMM chain.
+static constexpr double R1_TOL = 2.2737367544323206e-13;   // 2^-42
+
+__global__ __launch_bounds__(256) void k_rank1_check(BigArgs a, const BigBlock *blocks, int NP)
+{
+    __shared__ double s_sum[256];
+    __shared__ int s_star;
+    __shared__ unsigned int s_bad;
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const BigBlock bk = blocks[blockIdx.x];
+    const SegDesc sd = a.segs[bk.seg];
+    if (bk.slab != 0 || (sd.first & SEG_FIRST) || (int)sd.len <= a.head_len) return;
+    const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
+    const double *P = a.P + gv * NP;
+    const int N = a.N;
+    for (int c = tid; c < N; c += blockDim.x) {
+        double t = 0.0;
+        for (int i = 0; i < N; ++i) t += P[(size_t)i * NP + c];
+        s_sum[c] = t;
+    }
+    if (tid == 0) s_bad = 0u;
+    __syncthreads();
+    if (tid == 0) {   // reference column: the largest one (exponent first, then stored sum)
+        int best = 0;
+        for (int c = 1; c < N; ++c) {
+            const int eb = a.EX[gv + best], ec = a.EX[gv + c];
+            if (ec > eb || (ec == eb && s_sum[c] > s_sum[best])) best = c;
+        }
+        s_star = best;
+    }
+    __syncthreads();
+    const int cs = s_star;
+    const double ss = s_sum[cs];
+    unsigned int bad = !(ss > 0.0 && ss < INFINITY);
+    for (int idx = tid; idx < N * N; idx += blockDim.x) {
+        const int i = idx / N, c = idx - i * N;
+        const double u = P[(size_t)i * NP + cs], v = P[(size_t)i * NP + c], sc = s_sum[c];
+        if (u == 0.0) bad |= (v != 0.0);
+        else {
+            const double r = (v * ss) / (u * sc);
+            bad |= !(fabs(r - 1.0) <= R1_TOL);     // NaN / inf / zero column -> not certified
+        }
+    }
+    if (bad) atomicOr(&s_bad, 1u);
+    __syncthreads();
+    const bool ok = s_bad == 0u;
+    const size_t r1 = ((size_t)b * a.n_segs + bk.seg) * NP;
+    if (tid == 0) a.r1flag[(size_t)b * a.n_segs + bk.seg] = ok ? 1 : 0;
+    if (ok)
+        for (int k = tid; k < NP; k += blockDim.x) {
+            a.r1u[r1 + k] = k < N ? P[(size_t)k * NP + cs] : 0.0;
+            a.r1alpha[r1 + k] = k < N ? s_sum[k] / ss : 0.0;
+        }
 }

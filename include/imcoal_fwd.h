@@ -144,6 +144,11 @@ int imc_dictionary_reset(void);
  * accumulated device milliseconds and launch counts since the last reset, and resets. */
 int imc_profile_enable(int on);
 int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propagate, uint64_t *n_stitch);
+/* Rank-one hand-off of the GEMM-chain kernels (long segments, N > 24): a segment's transfer operator is tested after
+ * a quarter of its tokens; if every column has collapsed onto one direction (component-wise, within 2^-44) the rest of
+ * the segment propagates that vector instead of the N x N operator.  For the last imc_forward* call: how many operator
+ * segments were tested and how many were certified.  IMC_RANK1=0 in the environment switches the hand-off off. */
+int imc_last_rank1(uint64_t *checked, uint64_t *collapsed);
 /* Description of the last launch plan, out8[0..7] = segments, vectors, per-column segment length,
  * executed vector-columns (per-column kernel), token segment length, executed vector-tokens (token
  * kernel), tokens in the compressed streams, token alphabet. */

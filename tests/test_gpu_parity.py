@@ -478,3 +478,34 @@ def test_state_export_split_alignment(oracle, n, mode):
     with pytest.raises(ValueError):
         forward_states([empty.handle], pis, Ts, Es, True)
     set_zip(1)
+
+
+@pytest.mark.parametrize("n,stay,expect", [(28, 0.9, "all"), (70, 0.9, "all"), (150, 0.9, "any"), (150, 0.95, "any"), (70, 0.99999, "any"), (70, -1.0, "none")])
+def test_rank_one_handoff(oracle, n, stay, expect):
+    """GEMM chain with long segments: operators that provably collapsed to rank one (fast-mixing HMM) finish on the
+    mat-vec chain, slow-mixing ones stay on the GEMM chain; either way the result is the oracle's."""
+    set_zip(1)
+    if stay < 0:        # uninformative emissions + sticky transitions: the operator stays close to the identity
+        hmms = [synth.random_hmm(n, 3, seed=9000 + n + b, stay=0.99999) for b in range(2)]
+        hmms = [(pi, T, np.tile(np.array([0.9, 0.06, 0.04]), (n, 1))) for pi, T, _ in hmms]
+    else:
+        hmms = [synth.random_hmm(n, 3, seed=9000 + n + b, stay=stay) for b in range(2)]
+    pis, Ts, Es = (np.stack([h[k] for h in hmms]) for k in range(3))
+    chunks = [compressible(120_000, seed=n + 11), compressible(40_000, seed=n + 12)]
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    try:
+        set_zip(5, reset=False)                       # raw column stream on the GEMM chain: segments of 4096 columns
+        set_seg(4096)
+        got = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+        plan = _capi.last_plan()
+        checked, collapsed = _capi.last_rank1()
+    finally:
+        set_seg(0)
+        set_zip(1)
+    assert "rank1-handoff" in plan["kernels"], plan["kernels"]
+    assert checked > 0
+    assert {"all": collapsed == checked, "any": True, "none": collapsed == 0}[expect], (checked, collapsed)
+    for b in range(2):
+        for k, c in enumerate(chunks):
+            want = oracle.forward_scaled(pis[b], Ts[b], Es[b], c)
+            assert rel_err(got[b][k], want) < TOL, (n, stay, b, k, got[b][k], want)
