@@ -73,7 +73,8 @@ constexpr size_t DICT_WIDE_MIN_COUNT = 6;          // ... in which a pair must o
 constexpr size_t CTAB_BUDGET = (size_t)24 << 30;   // largest operator table (all parameter sets) a plan may allocate
 constexpr size_t R1_MIN_SEGLEN = 1024;             // rank-one hand-off: segments at least this long (stream elements) ...
 constexpr size_t R1_MIN_HEAD = 256;                // ... run at least this many on the GEMM chain before the test
-constexpr double R1_HEAD_COLUMNS = 65536.0;        // ... and about this many alignment columns
+constexpr double R1_HEAD_COLUMNS = 65536.0;        // ... and about this many alignment columns (first call of a plan)
+constexpr double R1_HEAD_MIN_COLUMNS = 8192.0;     // ... never fewer than this however well the tests go
 
 struct DictDev {                                   // one trained dictionary + its device copy
     imc::PairDict dict;
@@ -371,7 +372,10 @@ struct Group {             // one propagate launch
     bool rank1 = false;
     int head_len = 0;
     std::vector<BigBlock> tail_blocks;        // one entry per segment (operator tails and first segments)
-    std::vector<uint32_t> r1_eligible;        // plan-wide ids of the operator segments longer than head_len
+    std::vector<std::pair<uint32_t, uint32_t>> r1_segs;   // (plan-wide id, length) of the operator segments
+    int head_min = 0, head_max = 0;           // the head adapts between these from call to call (collect_rank1_stats)
+    bool head_frozen = false;                 // a test failed once: no further shortening
+    int head_good = 0;                        // last head length at which every test passed
     BigBlock *d_tail_blocks = nullptr;
     int *d_r1flag = nullptr;
     double *d_r1u = nullptr, *d_r1alpha = nullptr;
@@ -677,7 +681,10 @@ struct PlanBuilder {
                 const double t_vec = table_mb > 128.0 ? np2 * 1.5 : matvec_step_cycles(np2, gr.A);
                 const double nseg = std::max(1.0, toks / (double)gr.seglen);
                 if (g.seg_override) {
-                    if (gr.seglen >= 4 * R1_MIN_HEAD) { gr.rank1 = true; gr.head_len = (int)round_up(gr.seglen / 4, 16); }
+                    if (gr.seglen >= 4 * R1_MIN_HEAD) {
+                        gr.rank1 = true;
+                        gr.head_len = gr.head_min = gr.head_max = (int)round_up(gr.seglen / 4, 16);
+                    }
                 } else {
                     double best = 1e300;
                     int best_m = 0;
@@ -692,6 +699,8 @@ struct PlanBuilder {
                         gr.rank1 = true;
                         gr.head_len = (int)head;
                         gr.seglen = std::max<size_t>(16, round_up(gr.seglen / best_m, 16));
+                        gr.head_min = (int)round_up(std::max<size_t>(64, (size_t)(R1_HEAD_MIN_COLUMNS / span)), 16);
+                        gr.head_max = (int)round_up(gr.seglen / 2, 16);
                     }
                 }
             }
@@ -874,7 +883,7 @@ struct PlanBuilder {
                 for (size_t i2 = 0; i2 < gr.seg_ids.size(); ++i2)
                 {
                     gr.tail_blocks.push_back(BigBlock{gr.seg_ids[i2], 0u, gr.seg_out[i2], 0u});   // (first segments included)
-                    if (!seg_first[gr.seg_ids[i2]] && (int)segs[gr.seg_ids[i2]].len > gr.head_len) gr.r1_eligible.push_back(gr.seg_ids[i2]);
+                    if (!seg_first[gr.seg_ids[i2]]) gr.r1_segs.push_back({gr.seg_ids[i2], segs[gr.seg_ids[i2]].len});
                 }
                 const size_t nrec = (size_t)B * segs.size();
                 if (e == hipSuccess) e = up((void **)&gr.d_tail_blocks, gr.tail_blocks.data(), gr.tail_blocks.size() * sizeof(BigBlock));
@@ -1145,19 +1154,37 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
     return IMC_OK;
 }
 
-// After a call has been synchronised: how many operator segments the rank-one test saw and how many it certified.
+// After a call has been synchronised: how many operator segments the rank-one test saw and how many it certified,
+// and the head length of the NEXT call of this plan: while every test passes the head shrinks by a quarter (the
+// HMM's memory is shorter than assumed); the first failure returns to the last length that passed everywhere and
+// stops the shrinking, later failures (the parameters moved) lengthen it by half.  Optimisers and MCMC
+// chains call with slowly moving parameters, so a few calls settle it; a failed test only costs that call its
+// speed-up (the segment finishes on the GEMM chain), never its result.
 void collect_rank1_stats(Plan *p)
 {
     g.r1_checked = g.r1_collapsed = 0;
-    for (const Group &gr : p->groups) {
-        if (!gr.rank1 || gr.r1_eligible.empty()) continue;
+    for (Group &gr : p->groups) {
+        if (!gr.rank1 || gr.r1_segs.empty()) continue;
         std::vector<int> flags((size_t)p->B * p->n_segs);
         if (hipMemcpy(flags.data(), gr.d_r1flag, flags.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) continue;
+        uint64_t checked = 0, collapsed = 0;
         for (int b = 0; b < p->B; ++b)
-            for (uint32_t sid : gr.r1_eligible) {
-                ++g.r1_checked;
-                g.r1_collapsed += flags[(size_t)b * p->n_segs + sid] ? 1 : 0;
+            for (const auto &sl : gr.r1_segs) {
+                if ((int)sl.second <= gr.head_len) continue;
+                ++checked;
+                collapsed += flags[(size_t)b * p->n_segs + sl.first] ? 1 : 0;
             }
+        g.r1_checked += checked;
+        g.r1_collapsed += collapsed;
+        if (!checked || g.seg_override) continue;
+        if (collapsed == checked) {
+            gr.head_good = gr.head_len;
+            if (!gr.head_frozen) gr.head_len = std::max(gr.head_min, (int)round_up((size_t)gr.head_len * 3 / 4, 16));
+        } else {   // back to the last length that passed everywhere (or half as long again if there is none above)
+            const int grown = (int)round_up((size_t)gr.head_len * 3 / 2, 16);
+            gr.head_len = std::min(gr.head_max, (gr.head_good > gr.head_len && !gr.head_frozen) ? gr.head_good : grown);
+            gr.head_frozen = true;
+        }
     }
 }
 
@@ -1418,6 +1445,7 @@ int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, 
     if (int rc = build_plan(chunks, n_chunks, N, S, B, false, &p)) return rc;
     // the pinned staging buffer is reused by the next call: wait for the previous upload first
     HIP_TRY(hipStreamSynchronize(st));
+    if (p->calls > 0) collect_rank1_stats(p);   // the previous call of this plan has finished: adapt the hand-off head
     stage_params(p, pis, Ts, Es);
     if (int rc = enqueue(p, st, p->d_out)) return rc;
     ++p->calls;
