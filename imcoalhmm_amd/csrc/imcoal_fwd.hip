@@ -485,6 +485,29 @@ static double matvec_step_cycles(double np2, int alphabet)
     return np2 / 3.0 * std::min(2.2, 1.0 + 0.03 * std::max(0.0, table_mb - 6.0));
 }
 
+// Rank-one hand-off estimate for a GEMM-chain group whose base plan has `nseg` segments of `seglen` elements (one
+// round of workgroups): m times the segments = m rounds of `head`-long GEMM heads, tails 1/m as long on the mat-vec
+// chain.  A tail step streams NP^2 doubles; with many chains that is the memory system's bandwidth (measured: 256
+// chains of a 1.6 GB table read 7 TB/s), with few it is one workgroup's latency.  Returns the best m (0: not
+// worth it) and its cycles.
+struct HandoffEstimate { int m; double cycles; };
+static HandoffEstimate estimate_handoff(double seglen, double nseg, int B, double head, double np, int alphabet, int cus)
+{
+    const double np2 = np * np, t_gemm = 0.027 * np2 * np + 20000.0;
+    const double table_mb = (double)alphabet * np2 * 8.0 / 1.0e6;
+    const double bw = table_mb > 128.0 ? 7.0e12 : table_mb > 16.0 ? 8.6e12 : 15.0e12;   // bytes/s: HBM, Infinity Cache, L2
+    HandoffEstimate best{0, 1e300};
+    for (int m = 1; m <= 6; ++m) {
+        const double sl = seglen / m;
+        if (sl < 2.0 * head) break;
+        const double chains = m * nseg * B, active = std::min(chains, (double)cus);
+        const double t_vec = std::max(np2 / 8.0 + 1500.0, active * np2 * 8.0 * 2.1e9 / bw) * std::max(1.0, chains / cus);
+        const double est = m * head * t_gemm + (sl - head) * t_vec;
+        if (est < best.cycles) best = HandoffEstimate{m, est};
+    }
+    return best;
+}
+
 // Builds one launch plan in phases; every phase reads what the earlier ones left in the members.
 struct PlanBuilder {
     const imc_obs *const *chunks;
@@ -504,6 +527,15 @@ struct PlanBuilder {
     struct HostLevel { std::vector<uint32_t> chunk_seg, vec0; std::vector<uint8_t> first; std::vector<ChainDesc> chains; uint32_t n_vecs; };
     std::vector<HostLevel> hl;          // stitch hierarchy, level 0 = propagate output
     std::vector<int32_t> final_vec;     // chunk -> its single remaining unit at the last level (-1: empty chunk)
+
+    // hand-off head of a group, in stream elements: ~R1_HEAD_COLUMNS alignment columns
+    size_t handoff_head(const Group &gr) const
+    {
+        double cols = 0.0, toks = 0.0;
+        for (int f : gr.chunks) { cols += (double)chunks[f]->L; toks += (double)(gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L); }
+        const double span = toks > 0.0 ? cols / toks : 1.0;
+        return round_up(std::max<size_t>(R1_MIN_HEAD, (size_t)(R1_HEAD_COLUMNS / span)), 16);
+    }
 
     void assign_groups()
     {
@@ -605,7 +637,12 @@ struct PlanBuilder {
                 for (size_t L : lens) lmax = std::max(lmax, L);
                 const double np2 = (double)kc->NP * kc->NP, per_cu_steps = (double)total * B / (double)g.cus;
                 const double cost_vec = std::max((double)lmax * (np2 / 8.0 + 1500.0), per_cu_steps * matvec_step_cycles(np2, gr.A));
-                const double cost_gemm = std::max(16.0, per_cu_steps) * (0.027 * np2 * kc->NP + 20000.0);
+                double cost_gemm = std::max(16.0, per_cu_steps) * (0.027 * np2 * kc->NP + 20000.0);
+                if (g.rank1_handoff && !g.seg_override && gr.seglen >= R1_MIN_SEGLEN) {   // GEMM heads + mat-vec tails
+                    const HandoffEstimate he = estimate_handoff((double)gr.seglen, std::max(1.0, (double)total / gr.seglen), B,
+                                                                (double)handoff_head(gr), kc->NP, gr.A, g.cus);
+                    if (he.m) cost_gemm = std::min(cost_gemm, he.cycles);
+                }
                 if (std::getenv("IMC_DEBUG"))
                     std::fprintf(stderr, "[imc] plan: GEMM chain seg %zu cost %.3g cycles; mat-vec chain cost %.3g cycles\n",
                                  gr.seglen, cost_gemm, cost_vec);
@@ -674,11 +711,7 @@ struct PlanBuilder {
                 double cols = 0.0, toks = 0.0;
                 for (int f : gr.chunks) { cols += (double)chunks[f]->L; toks += (double)(gr.zip ? chunks[f]->ntok[gr.level] : chunks[f]->L); }
                 const double span = toks > 0.0 ? cols / toks : 1.0;
-                const size_t head = round_up(std::max<size_t>(R1_MIN_HEAD, (size_t)(R1_HEAD_COLUMNS / span)), 16);
-                const double np2 = (double)kc->NP * kc->NP, t_gemm = 0.027 * np2 * kc->NP + 20000.0;
-                const double table_mb = (double)gr.A * np2 * 8.0 / 1.0e6;
-                // a lone chain streams its operators at ~11 GB/s from HBM (measured, 1.6 GB table), faster from the caches
-                const double t_vec = table_mb > 128.0 ? np2 * 1.5 : matvec_step_cycles(np2, gr.A);
+                const size_t head = handoff_head(gr);
                 const double nseg = std::max(1.0, toks / (double)gr.seglen);
                 if (g.seg_override) {
                     if (gr.seglen >= 4 * R1_MIN_HEAD) {
@@ -686,15 +719,7 @@ struct PlanBuilder {
                         gr.head_len = gr.head_min = gr.head_max = (int)round_up(gr.seglen / 4, 16);
                     }
                 } else {
-                    double best = 1e300;
-                    int best_m = 0;
-                    for (int m = 1; m <= 6; ++m) {
-                        const double sl = (double)gr.seglen / m;
-                        if (sl < 2.0 * head) break;
-                        const double share = std::max(1.0, m * nseg / (double)g.cus);
-                        const double est = m * (double)head * t_gemm + (sl - head) * t_vec * share;
-                        if (est < best) { best = est; best_m = m; }
-                    }
+                    const int best_m = estimate_handoff((double)gr.seglen, nseg, B, (double)head, kc->NP, gr.A, g.cus).m;
                     if (best_m) {
                         gr.rank1 = true;
                         gr.head_len = (int)head;
