@@ -438,7 +438,7 @@ def test_wide_token_levels(oracle, n):
         assert rel_err(got[0], raw) < TOL, (n, label)
 
 
-@pytest.mark.parametrize("n,mode", [(3, 1), (10, 0), (20, 1), (20, 2), (28, 3), (40, 1), (70, 1), (150, 1)])
+@pytest.mark.parametrize("n,mode", [(3, 1), (10, 0), (20, 1), (20, 2), (28, 3), (40, 1), (70, 1), (70, 5), (150, 1)])
 def test_state_export_split_alignment(oracle, n, mode):
     """imc_forward_state: one alignment cut into contiguous slices (as `dist.SplitAlignmentLikelihood` does
     across GPUs) - vector from the first slice, exact transfer operators from the others - recombines to the
@@ -452,7 +452,7 @@ def test_state_export_split_alignment(oracle, n, mode):
     pieces = [whole[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
     fw = [Forwarder.from_array(p, 3) for p in pieces]
     fw_whole = Forwarder.from_array(whole, 3)
-    for seg in (0, 256):
+    for seg in (0, 256) + ((4096,) if mode == 5 else ()):     # (mode 5 + 4096: GEMM chain with the rank-one hand-off)
         try:
             set_seg(seg)
             vec, vexp = forward_states([fw[0].handle], pis, Ts, Es, as_operator=False)
