@@ -1201,7 +1201,7 @@ void collect_rank1_stats(Plan *p)
             }
         g.r1_checked += checked;
         g.r1_collapsed += collapsed;
-        if (!checked || g.seg_override) continue;
+        if (!checked || g.seg_override || p->graph) continue;   // (a captured graph has the head length baked in)
         if (collapsed == checked) {
             gr.head_good = gr.head_len;
             if (!gr.head_frozen) gr.head_len = std::max(gr.head_min, (int)round_up((size_t)gr.head_len * 3 / 4, 16));
