@@ -89,3 +89,35 @@ def test_random_split_state(oracle, case):
         got = combine_states(vec[b, 0], vexp[b, 0], ops[b] if len(fw) > 1 else [], oexp[b] if len(fw) > 1 else [])
         want = oracle.forward_scaled(*hmms[b], whole)
         assert rel_err(got, want) < 1e-11, (case, n, nsym, mode, seg, B, cuts, kernels, b, got, want)
+
+
+@pytest.mark.parametrize("case", range(max(24, N_CASES // 8)))
+def test_random_handoff(oracle, case):
+    """Long GEMM-chain segments with the certified rank-one hand-off: random state counts, stickiness (so that some
+    segments collapse and some do not), segment lengths and batch sizes, against the oracle."""
+    rng = np.random.default_rng(9100 + case)
+    L = _capi.lib()
+    n = int(rng.choice([28, 48, 64, 70, 100, 150]))
+    B = int(rng.choice([1, 2]))
+    seg = int(rng.choice([2048, 4096, 8192]))
+    lens = [int(rng.choice([30_000, 70_000, 150_000 if n <= 100 else 90_000])) for _ in range(int(rng.integers(1, 3)))]
+    hmms = [synth.random_hmm(n, 3, seed=case * 10 + b, stay=float(rng.choice([0.5, 0.9, 0.99, 0.999, 0.9999]))) for b in range(B)]
+    if rng.random() < 0.25:                                   # uninformative emissions: no collapse at all
+        hmms = [(pi, T, np.tile(np.array([0.85, 0.1, 0.05]), (n, 1))) for pi, T, _ in hmms]
+    chunks = [_chunk(rng, 3, x) for x in lens]
+    try:
+        _capi.check(L.imc_set_compression(5))                 # raw stream, GEMM chain pinned
+        _capi.check(L.imc_set_segment_length(seg))
+        fw = [Forwarder.from_array(c, 3) for c in chunks]
+        got = forward_chunks_batch([f.handle for f in fw], np.stack([h[0] for h in hmms]), np.stack([h[1] for h in hmms]),
+                                   np.stack([h[2] for h in hmms]), per_chunk=True)
+        kernels = _capi.last_plan()["kernels"]
+        stats = _capi.last_rank1()
+    finally:
+        L.imc_set_compression(1)
+        L.imc_set_segment_length(0)
+    assert "rank1-handoff" in kernels and stats[0] > 0, (kernels, stats)
+    for b in range(B):
+        for f, c in enumerate(chunks):
+            want = oracle.forward_scaled(*hmms[b], c)
+            assert rel_err(got[b, f], want) < 1e-11, (case, n, seg, B, lens, stats, b, f, got[b, f], want)
