@@ -522,16 +522,26 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
         const int row = ps * ROWS_PER_PASS + wave * 4 + lg;
         rowoff[ps] = row * NP + W * lm;
     }
+    // The table is zero beyond N: the padded rows (last pass) and the padded columns (last piece of a row) are not
+    // fetched at all - their registers stay 0 - which saves up to 12 % of the streamed bytes (N = 150 in NP = 160).
+    const bool last_rows_live = (PASSES - 1) * ROWS_PER_PASS + wave * 4 + lg < a.N;
+    const bool last_cols_live = W * lm + 16 * W * (NJ - 1) < a.N;
     double av[PASSES][NT];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) av[ps][j] = 0.0;
 #define BV_LOAD(ps_, src_)                                                                          \
     do {                                                                                            \
         _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                         \
-            if constexpr (W == 2) {                                                                 \
-                const double2 v_ = *reinterpret_cast<const double2 *>((src_) + rowoff[ps_] + 32 * jj); \
-                av[ps_][2 * jj] = v_.x;                                                             \
-                av[ps_][2 * jj + 1] = v_.y;                                                         \
-            } else {                                                                                \
-                av[ps_][jj] = (src_)[rowoff[ps_] + 16 * jj];                                        \
+            if (((ps_) < PASSES - 1 || last_rows_live) && (jj < NJ - 1 || last_cols_live)) {        \
+                if constexpr (W == 2) {                                                             \
+                    const double2 v_ = *reinterpret_cast<const double2 *>((src_) + rowoff[ps_] + 32 * jj); \
+                    av[ps_][2 * jj] = v_.x;                                                         \
+                    av[ps_][2 * jj + 1] = v_.y;                                                     \
+                } else {                                                                            \
+                    av[ps_][jj] = (src_)[rowoff[ps_] + 16 * jj];                                    \
+                }                                                                                   \
             }                                                                                       \
         }                                                                                           \
     } while (0)
