@@ -1540,6 +1540,14 @@ const char *imc_last_kernels(void)
     return copy.c_str();
 }
 
+int imc_set_rank1_handoff(int on)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g.rank1_handoff != (on != 0)) drop_plans();   // cached plans were built for the other setting
+    g.rank1_handoff = on != 0;
+    return IMC_OK;
+}
+
 int imc_last_rank1(uint64_t *checked, uint64_t *collapsed)
 {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -149,6 +149,8 @@ int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propag
  * the segment propagates that vector instead of the N x N operator.  For the last imc_forward* call: how many operator
  * segments were tested and how many were certified.  IMC_RANK1=0 in the environment switches the hand-off off. */
 int imc_last_rank1(uint64_t *checked, uint64_t *collapsed);
+/* Switch the hand-off on (default) or off for plans built from now on (A/B comparisons, tests). */
+int imc_set_rank1_handoff(int on);
 /* Description of the last launch plan, out8[0..7] = segments, vectors, per-column segment length,
  * executed vector-columns (per-column kernel), token segment length, executed vector-tokens (token
  * kernel), tokens in the compressed streams, token alphabet. */

@@ -62,3 +62,35 @@ def test_full_size_segmentation_invariance_and_spot_check(big, hmm_params, oracl
     head = obs[:2_000_000]
     got = Forwarder.from_array(head, 3).forward(pi, T, E)
     assert rel_err(got, oracle.forward_scaled(pi, T, E, head)) < 1e-11
+
+
+def test_full_size_150_states_handoff_on_off_and_closed_form(big, hmm_params):
+    """BASELINE config 3 (150 states, the same 1e8 columns): the certified rank-one hand-off changes the work, not the
+    value - on/off agree to 1e-13 relative, repeated calls (the head length adapts between them) are identical to
+    that level, and a rank-one T reproduces the count-only closed form through the same kernels."""
+    obs, f = big
+    pi, T, E = hmm_params("im150_t0")
+    L = _capi.lib()
+    try:
+        _capi.check(L.imc_set_rank1_handoff(1))
+        on = [f.forward(pi, T, E) for _ in range(4)]
+        stats = _capi.last_rank1()
+        kernels = _capi.last_plan()["kernels"]
+        _capi.check(L.imc_set_rank1_handoff(0))
+        off = f.forward(pi, T, E)
+        assert "rank1" not in _capi.last_plan()["kernels"]
+    finally:
+        _capi.check(L.imc_set_rank1_handoff(1))
+    assert "rank1-handoff" in kernels and stats[0] > 100 and stats[1] > 0, (kernels, stats)
+    assert math.isfinite(off) and all(rel_err(v, off) < 1e-13 for v in on), (on, off)
+    n, nsym = 150, 3
+    rng = np.random.default_rng(12)
+    q = rng.random(n); q /= q.sum()
+    Tq = np.tile(q, (n, 1))
+    Eq = rng.random((n, nsym)); Eq /= Eq.sum(axis=1, keepdims=True)
+    piq = rng.random(n); piq /= piq.sum()
+    cnt = np.bincount(obs[1:], minlength=nsym)
+    want = math.log(piq @ Eq[:, obs[0]]) + float(cnt @ np.log(q @ Eq))
+    got = f.forward(piq, Tq, Eq)
+    assert _capi.last_rank1()[1] == _capi.last_rank1()[0] > 0       # a rank-one T collapses at once
+    assert rel_err(got, want) < 1e-10, (got, want)
