@@ -1,14 +1,18 @@
-// kernels_big.hpp - forward propagate as a chain of dense N x N products on the matrix cores.  Included by
-// imcoal_fwd.hip.  Used for 64 < N <= 192 and, when chunks are long, for 24 < N <= 64.
+// kernels_big.hpp - the kernels whose operator table lives in global memory.  Included by imcoal_fwd.hip.
+// Used for 64 < N <= 256 and, when chunks are long, for 24 < N <= 64.
 //
 // For N ~ 150 neither the N x N operators (180 KB each) nor a segment's transfer operator fit one wavefront's
 // registers, and the work per token step, P <- C_tok * P (N x N by N x N), is a genuine dense fp64 GEMM.  This is
 // the one place where the matrix cores are the right tool ("MFMA becomes relevant only if the
 // N^3 transfer-operator formulation is adopted"): v_mfma_f64_16x16x4_f64 tiles, NP = 16 NT.
-//   * k_big_table_raw / k_big_table_level build the per-evaluation operator table in global memory (L2-resident),
-//     one launch per dictionary depth; big_gemm is their workgroup-wide product (k panels staged through LDS).
-//   * k_big_propagate keeps a column slab of P resident in LDS for the whole launch and streams only the token
-//     operator's A panels; see the comment above the kernel.
+//   * k_big_table_raw / k_big_table_level build the per-evaluation operator table (up to 16384 tokens), one launch
+//     per dictionary depth; big_gemm is their workgroup-wide product (k panels staged through LDS).
+//   * k_big_propagate (one tile-row per wavefront) and k_big_propagate_s (NT = 6, 10, 14: tiles dealt over eight
+//     wavefronts so that the four SIMDs carry equal MFMA work) keep a column slab of P resident in LDS for the whole
+//     launch and stream only the token operator's A panels: the GEMM chain.
+//   * k_big_vector is the mat-vec chain x <- C_tok x for segments that are vectors: every chunk when a call has enough
+//     (chunk, parameter set) chains to fill the chip, first segments, and - TAIL variant - the tails of operator
+//     segments whose head k_rank1_check has certified to be rank one (the rank-one hand-off).
 // Every step is rescaled by one exact power of two (the exponent of the largest entry).
 #pragma once
 #include "kernels_plain.hpp"
