@@ -646,7 +646,8 @@ struct PlanBuilder {
                 if (std::getenv("IMC_DEBUG"))
                     std::fprintf(stderr, "[imc] plan: GEMM chain seg %zu cost %.3g cycles; mat-vec chain cost %.3g cycles\n",
                                  gr.seglen, cost_gemm, cost_vec);
-                if (!op_mode && (g.kernel_pref == 1 || (g.kernel_pref == 0 && cost_vec < cost_gemm))) {
+                // (no chunk longer than a segment: there would be no operator segments anyway)
+                if (!op_mode && (g.kernel_pref == 1 || (g.kernel_pref == 0 && (cost_vec < cost_gemm || lmax <= gr.seglen)))) {
                     gr.bigvec = true;
                     gr.seglen = std::max<size_t>(16, round_up(lmax, 16));
                 }
