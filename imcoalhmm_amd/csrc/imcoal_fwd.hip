@@ -329,7 +329,8 @@ KernelChoice kChoices[] = {
     make_kc<4, 1, 2>(), make_kc<4, 2, 2>(), make_kc<4, 3, 2>(), make_kc<4, 4, 2>(), make_kc<4, 5, 2>(),
     make_kc<3, 8, 2>(), make_kc<2, 14, 2>(), make_kc<2, 16, 2>(), make_kc<2, 20, 1>(), make_kc<1, 48, 1>(),
     make_kc<1, 56, 1>(), make_kc<1, 64, 1>(),
-    make_big<6, 1>(), make_big<8, 2>(), make_big<10, 2>(), make_big<12, 3>(), make_big<14, 7>(), make_big<16, 8>(),
+    make_big<6, 1>(), make_big<7, 1>(), make_big<8, 2>(), make_big<9, 3>(), make_big<10, 2>(), make_big<12, 3>(), make_big<14, 7>(),
+    make_big<16, 8>(),
 };
 constexpr int IMC_MAX_N = 256;
 
@@ -491,9 +492,10 @@ static double matvec_step_cycles(double np2, int alphabet)
 // chains of a 1.6 GB table read 7 TB/s), with few it is one workgroup's latency.  Returns the best m (0: not
 // worth it) and its cycles.
 struct HandoffEstimate { int m; double cycles; };
-static HandoffEstimate estimate_handoff(double seglen, double nseg, int B, double head, double np, int alphabet, int cus)
+static HandoffEstimate estimate_handoff(double seglen, double nseg, int B, double head, double np, int nslab, int alphabet, int cus)
 {
-    const double np2 = np * np, t_gemm = 0.027 * np2 * np + 20000.0;
+    // (a segment's GEMM step is shared by its nslab column-slab workgroups)
+    const double np2 = np * np, t_gemm = 0.027 * np2 * np / nslab + 20000.0;
     const double table_mb = (double)alphabet * np2 * 8.0 / 1.0e6;
     const double bw = table_mb > 128.0 ? 7.0e12 : table_mb > 16.0 ? 8.6e12 : 15.0e12;   // bytes/s: HBM, Infinity Cache, L2
     HandoffEstimate best{0, 1e300};
@@ -501,7 +503,7 @@ static HandoffEstimate estimate_handoff(double seglen, double nseg, int B, doubl
         const double sl = seglen / m;
         if (sl < 2.0 * head) break;
         const double chains = m * nseg * B, active = std::min(chains, (double)cus);
-        const double t_vec = std::max(np2 / 8.0 + 1500.0, active * np2 * 8.0 * 2.1e9 / bw) * std::max(1.0, chains / cus);
+        const double t_vec = std::max(np2 / 4.5 + 1500.0, active * np2 * 8.0 * 2.1e9 / bw) * std::max(1.0, chains / cus);
         const double est = m * head * t_gemm + (sl - head) * t_vec;
         if (est < best.cycles) best = HandoffEstimate{m, est};
     }
@@ -572,7 +574,7 @@ struct PlanBuilder {
                         double lmax = 0.0;   // or the mat-vec chain kernel, when no chunk needs splitting
                         for (int f : kv.second) lmax = std::max(lmax, (double)chunks[f]->ntok[l]);
                         const double np2 = (double)kc->NP * kc->NP;
-                        const double c_vec = std::max(lmax * (np2 / 8.0 + 1500.0), toks * B / (double)g.cus * matvec_step_cycles(np2, o0->alphabet[l]));
+                        const double c_vec = std::max(lmax * (np2 / 4.5 + 1500.0), toks * B / (double)g.cus * matvec_step_cycles(np2, o0->alphabet[l]));
                         if (!op_mode && (g.kernel_pref == 1 || (g.kernel_pref == 0 && c_vec < c_main))) c_main = c_vec;
                     } else {     // ~5200 cycles per row-step at N=20; every workgroup rebuilds the table
                         c_tab = (o0->alphabet[l] - S) * (400.0 + n3 / 64.0);
@@ -636,11 +638,11 @@ struct PlanBuilder {
                 size_t lmax = 0;
                 for (size_t L : lens) lmax = std::max(lmax, L);
                 const double np2 = (double)kc->NP * kc->NP, per_cu_steps = (double)total * B / (double)g.cus;
-                const double cost_vec = std::max((double)lmax * (np2 / 8.0 + 1500.0), per_cu_steps * matvec_step_cycles(np2, gr.A));
+                const double cost_vec = std::max((double)lmax * (np2 / 4.5 + 1500.0), per_cu_steps * matvec_step_cycles(np2, gr.A));
                 double cost_gemm = std::max(16.0, per_cu_steps) * (0.027 * np2 * kc->NP + 20000.0);
                 if (g.rank1_handoff && !g.seg_override && gr.seglen >= R1_MIN_SEGLEN) {   // GEMM heads + mat-vec tails
                     const HandoffEstimate he = estimate_handoff((double)gr.seglen, std::max(1.0, (double)total / gr.seglen), B,
-                                                                (double)handoff_head(gr), kc->NP, gr.A, g.cus);
+                                                                (double)handoff_head(gr), kc->NP, kc->big_nslab, gr.A, g.cus);
                     if (he.m) cost_gemm = std::min(cost_gemm, he.cycles);
                 }
                 if (std::getenv("IMC_DEBUG"))
@@ -720,7 +722,7 @@ struct PlanBuilder {
                         gr.head_len = gr.head_min = gr.head_max = (int)round_up(gr.seglen / 4, 16);
                     }
                 } else {
-                    const int best_m = estimate_handoff((double)gr.seglen, nseg, B, (double)head, kc->NP, gr.A, g.cus).m;
+                    const int best_m = estimate_handoff((double)gr.seglen, nseg, B, (double)head, kc->NP, kc->big_nslab, gr.A, g.cus).m;
                     if (best_m) {
                         gr.rank1 = true;
                         gr.head_len = (int)head;
@@ -961,6 +963,28 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
 
     KernelChoice *kc = choose_kernel(N, prefer_gemm);
     if (!kc) return fail(IMC_ERR_ARG, "N exceeds the largest built kernel (" + std::to_string(IMC_MAX_N) + ")");
+    if (kc->R == 0 && (kc->G == 7 || kc->G == 9) && kc + 1 < kChoices + sizeof(kChoices) / sizeof(kChoices[0])) {
+        // The odd tile counts (NP = 112, 144) pad less, but run one workgroup per segment: their base segments are
+        // half as long as the next shape's (two column slabs per segment), which on mid-sized inputs can fall below
+        // what the rank-one hand-off needs.  Take the next shape when it can hand off and this one cannot.
+        double toks = 0.0, cols = 0.0;
+        for (int f = 0; f < n_chunks; ++f) {
+            size_t nt = chunks[f]->L;
+            if (g.compression && chunks[f]->dict && chunks[f]->nsym == S)
+                for (int l = 0; l < imc::kNumLevels; ++l)
+                    if (chunks[f]->d_tok[l]) nt = std::min(nt, chunks[f]->ntok[l]);
+            toks += (double)nt;
+            cols += (double)chunks[f]->L;
+        }
+        const double head = std::max<double>((double)R1_MIN_HEAD, R1_HEAD_COLUMNS / std::max(1.0, cols / std::max(1.0, toks)));
+        auto eligible = [&](const KernelChoice *k) {
+            const double per_cu = (double)std::max<size_t>(1, std::min<size_t>(LDS_BUDGET / k->big_lds, (size_t)32 / (size_t)k->G));
+            const double target = std::max(1.0, (double)g.cus * per_cu / ((double)B * k->big_nslab));
+            const double seglen = toks / target;
+            return seglen >= (double)R1_MIN_SEGLEN && seglen >= 2.0 * head;
+        };
+        if (g.rank1_handoff && !g.seg_override && !eligible(kc) && eligible(kc + 1)) kc = kc + 1;
+    }
     auto p = std::make_unique<Plan>();
     p->key = key; p->kc = kc; p->N = N; p->S = S; p->B = B; p->n_chunks = n_chunks;
     PlanBuilder pb{chunks, n_chunks, N, S, B, op_mode, kc, std::move(p)};

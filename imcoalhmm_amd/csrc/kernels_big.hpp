@@ -458,7 +458,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
 template <int NT>
 struct BigVec {
     // every pass covers 4 WAVES rows and the passes tile NP = 16 NT rows exactly; <= 48 operator doubles per lane
-    static constexpr int WAVES = NT == 3 ? 12 : NT == 14 ? 14 : NT > 12 ? 16 : 8;
+    static constexpr int WAVES = NT == 3 ? 12 : (NT == 7 || NT == 9 || NT == 14) ? NT : NT > 12 ? 16 : 8;
     static constexpr bool PIPELINED = NT <= 10;      // beyond that the double set of operator registers would spill
     // not pipelined: all of a step's loads are issued before its first use while they fit the registers (NT = 12;
     // measured at NT = 10: loading pass by pass instead costs 50 %), pass by pass beyond
