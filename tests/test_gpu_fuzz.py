@@ -27,7 +27,7 @@ def _chunk(rng, nsym, L):
 def test_random_dispatch(oracle, case):
     rng = np.random.default_rng(1000 + case)
     L = _capi.lib()
-    n = int(rng.choice([1, 2, 3, 5, 8, 10, 13, 16, 20, 22, 24, 27, 32, 40, 47, 64, 65, 90, 128, 150, 192, 200, 256]))
+    n = int(rng.choice([1, 2, 3, 5, 8, 10, 13, 16, 20, 22, 24, 27, 32, 40, 47, 64, 65, 90, 100, 128, 140, 150, 192, 200, 256]))
     nsym = int(rng.choice([2, 3, 3, 3, 4, 7]))
     mode = int(rng.integers(0, 6))
     seg = int(rng.choice([0, 0, 16, 48, 256, 1000]))
@@ -97,7 +97,7 @@ def test_random_handoff(oracle, case):
     segments collapse and some do not), segment lengths and batch sizes, against the oracle."""
     rng = np.random.default_rng(9100 + case)
     L = _capi.lib()
-    n = int(rng.choice([28, 48, 64, 70, 100, 150]))
+    n = int(rng.choice([28, 48, 64, 70, 100, 140, 150]))
     B = int(rng.choice([1, 2]))
     seg = int(rng.choice([2048, 4096, 8192]))
     lens = [int(rng.choice([30_000, 70_000, 150_000 if n <= 100 else 90_000])) for _ in range(int(rng.integers(1, 3)))]

@@ -78,7 +78,7 @@ def test_segmentation_invariance(hmm_params, example_pairs, golden_loglik, seg, 
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 8, 10, 12, 13, 16, 17, 20, 21, 24, 25, 28, 29, 32, 33, 40, 41, 48, 50, 56, 57, 64,
-                               65, 96, 97, 128, 150, 160, 161, 192, 200, 225, 256])
+                               65, 96, 97, 112, 113, 128, 129, 144, 145, 150, 160, 161, 192, 200, 225, 256])
 @pytest.mark.parametrize("nsym", [3])
 def test_random_hmms_all_kernel_shapes(oracle, n, nsym):
     """Every (R,G) instantiation, padded and unpadded N, with stitching forced (seg=160)."""
@@ -353,7 +353,7 @@ def test_maximum_likelihood_estimate_improves(hmm_params_file, example_pairs):
     assert len(log.getvalue().splitlines()[0].split("\t")) == 3
 
 
-@pytest.mark.parametrize("n", [70, 100, 150, 192, 210, 256])
+@pytest.mark.parametrize("n", [70, 100, 140, 150, 192, 210, 256])
 @pytest.mark.parametrize("mode", [2, 4], ids=["tokens", "raw"])
 def test_matvec_chain_kernel_large_n(oracle, n, mode):
     """N > 64 with one segment per chunk (pinned by the 'vector' modes): the mat-vec chain kernel, batch of 3."""
