@@ -147,7 +147,10 @@ int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propag
 /* Rank-one hand-off of the GEMM-chain kernels (long segments, N > 24): a segment's transfer operator is tested after
  * a quarter of its tokens; if every column has collapsed onto one direction (component-wise, within 2^-44) the rest of
  * the segment propagates that vector instead of the N x N operator.  For the last imc_forward* call: how many operator
- * segments were tested and how many were certified.  IMC_RANK1=0 in the environment switches the hand-off off. */
+ * segments were tested and how many were certified.  IMC_RANK1=0 in the environment switches the hand-off off.
+ * The head length adapts between calls of the same plan, so a repeated call may differ from the previous one in the
+ * last bits (different association; observed: identical to 16 digits); switch the hand-off off for bit-for-bit
+ * repeatability across calls. */
 int imc_last_rank1(uint64_t *checked, uint64_t *collapsed);
 /* Switch the hand-off on (default) or off for plans built from now on (A/B comparisons, tests). */
 int imc_set_rank1_handoff(int on);
