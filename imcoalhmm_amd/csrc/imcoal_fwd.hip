@@ -512,10 +512,10 @@ static HandoffEstimate estimate_handoff(double seglen, double nseg, int B, doubl
 
 // Builds one launch plan in phases; every phase reads what the earlier ones left in the members.
 struct PlanBuilder {
-    const imc_obs *const *chunks;
-    int n_chunks, N, S, B;
-    bool op_mode;                       // imc_forward_state(as_operator): no segment is a chunk's "first"
-    KernelChoice *kc;
+    const imc_obs *const *chunks = nullptr;
+    int n_chunks = 0, N = 0, S = 0, B = 0;
+    bool op_mode = false;               // imc_forward_state(as_operator): no segment is a chunk's "first"
+    KernelChoice *kc = nullptr;
     std::unique_ptr<Plan> p;
     bool big = false;                   // GEMM-chain / mat-vec chain kernels (global-memory operator table)
     std::vector<int> chunk_group;       // chunk -> index into p->groups
@@ -987,7 +987,9 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     }
     auto p = std::make_unique<Plan>();
     p->key = key; p->kc = kc; p->N = N; p->S = S; p->B = B; p->n_chunks = n_chunks;
-    PlanBuilder pb{chunks, n_chunks, N, S, B, op_mode, kc, std::move(p)};
+    PlanBuilder pb;
+    pb.chunks = chunks; pb.n_chunks = n_chunks; pb.N = N; pb.S = S; pb.B = B; pb.op_mode = op_mode; pb.kc = kc;
+    pb.p = std::move(p);
     pb.assign_groups();
     pb.choose_segment_lengths();
     pb.cut_segments();
