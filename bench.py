@@ -5,17 +5,22 @@ A "step" is one evaluation of the summed log-likelihood (one pass of the hot pat
 job's synthetic alignment chunks, which are resident in HBM before the timed region starts; the
 per-step host input is only (pi, T, E) (a few KB), exactly what Forwarder.forward receives.
 
-  N=1  : BASELINE config[1] - isolation model, 20 states, 1 x 100 Mbp synthetic pairwise alignment
-  N>1  : BASELINE config[3] sliced per GPU - 32 x 10 Mbp chunks per rank (256 chunks at N=8),
-         chunks sharded statically, one RCCL all-reduce(sum) of the partial log-likelihoods per step.
+  --gpus 1 : BASELINE config[1] - isolation model, 20 states, 1 x 100 Mbp synthetic pairwise alignment
+             (--workload config4-slice gives the per-GPU slice of the multi-GPU workload on one GPU)
+  --gpus N : BASELINE config[3] sliced per GPU - 32 x 10 Mbp chunks per rank (256 chunks at N=8),
+             chunks sharded statically, one RCCL all-reduce(sum) of the partial log-likelihoods per step.
+             Launched by the driver under torch.distributed.run; run directly (no WORLD_SIZE in the
+             environment) it starts its own N rank processes before anything touches the GPU.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` and, at N=1,
-`cpu_baseline`.
+`cpu_baseline` and `extra_configs` (the other BASELINE configs at their per-GPU size, a few steps each).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,10 +30,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 fp64 FMA lanes x 2 x 2.4 GHz
+FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 fp64 FMA lanes x 2 x 2.4 GHz; the fp64 MFMA peak is the same
+PIECE = 10_000_000             # synthetic alignments are generated in pieces of this many columns
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -36,11 +42,14 @@ def main():
     ap.add_argument("--states", type=int, default=20)
     ap.add_argument("--fixture", type=str, default="",
                     help="(pi,T,E) fixture key in tests/golden/hmm_params.npz, e.g. im150_t0 (default iso<states>_t0)")
+    ap.add_argument("--workload", choices=("auto", "config2", "config4-slice"), default="auto",
+                    help="auto: config2 (1 x 1e8 columns) on one GPU, config4-slice (32 x 1e7 per rank) on several")
     ap.add_argument("--columns", type=int, default=0, help="override columns per chunk")
     ap.add_argument("--chunks", type=int, default=0, help="override chunks per rank")
     ap.add_argument("--batch", type=int, default=1,
                     help="parameter sets evaluated per step (BASELINE config[4] uses 64 proposals/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs leg (profiling runs)")
     ap.add_argument("--no-compress", action="store_true",
                     help="raw symbol stream (one step per alignment column), kernel chosen automatically")
     ap.add_argument("--mode", type=int, default=-1, help="imc_set_compression mode 0..5 (overrides --no-compress)")
@@ -51,19 +60,138 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses device 0 and the reduction runs "
                          "over gloo (RCCL refuses two ranks on one device); never used for reported numbers")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="launcher / reduction rehearsal without any GPU: ranks evaluate a stand-in partial sum on the "
+                         "host and reduce over gloo (tests/test_bench_launcher.py); prints a line marked invalid")
+    return ap.parse_args(argv)
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a torchrun environment: start the N rank processes ourselves.  This parent
+    has not imported torch or touched HIP, so nothing GPU-related is inherited; it only forwards the exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def _gen_piece(task):
+    key, n, seed = task
+    from imcoalhmm_amd import synth
+    d = np.load(os.path.join(REPO, "tests", "golden", "hmm_params.npz"))
+    return synth.sample_alignment(d[key + "_pi"], d[key + "_T"], d[key + "_E"], n, seed=seed)
+
+
+def generate(requests):
+    """requests: list of (tag, fixture key, columns, seed) -> {tag: uint8 array}.  Pieces of <= 1e7 columns are sampled
+    in a fork pool - this runs BEFORE the first library / HIP call of the process, so the children inherit no GPU state."""
+    tasks, index = [], []
+    for tag, key, cols, seed in requests:
+        for k, off in enumerate(range(0, cols, PIECE)):
+            tasks.append((key, min(PIECE, cols - off), seed * 1000 + k))
+            index.append(tag)
+    workers = max(1, min(len(tasks), os.cpu_count() or 1, 16))
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            pieces = pool.map(_gen_piece, tasks, chunksize=1)
+    else:
+        pieces = [_gen_piece(t) for t in tasks]
+    out = {}
+    for tag, p in zip(index, pieces):
+        out.setdefault(tag, []).append(p)
+    return {tag: (ps[0] if len(ps) == 1 else np.concatenate(ps)) for tag, ps in out.items()}
+
+
+def read_profile(lib):
+    ms_p, ms_s = ctypes.c_double(), ctypes.c_double()
+    n_p, n_s = ctypes.c_uint64(), ctypes.c_uint64()
+    lib.imc_profile_read(ctypes.byref(ms_p), ctypes.byref(ms_s), ctypes.byref(n_p), ctypes.byref(n_s))
+    return ms_p.value / max(n_p.value, 1), ms_s.value / max(n_s.value, 1)
+
+
+def timed_steps(lib, step, steps, warmup, fence):
+    """W untimed + K timed calls of step(), bracketed by fence(); HIP-event kernel timing over the timed region."""
+    value = None
+    for _ in range(warmup):
+        value = step()
+    lib.imc_profile_enable(1)
+    read_profile(lib)                                  # reset
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        value = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    k_ms, s_ms = read_profile(lib)
+    lib.imc_profile_enable(0)
+    return value, elapsed, k_ms, s_ms
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(self_launch(args))
+    world = int(world_env) if world_env is not None else 1
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with --nproc-per-node equal to --gpus" % (world, args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = args.gpus
-    if world != n_gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, n_gpus))
+    if args.rehearse_cpu:
+        return rehearse_cpu(args, rank, world)
+
+    d = np.load(os.path.join(REPO, "tests", "golden", "hmm_params.npz"))
+    key = args.fixture or "iso%d_t0" % args.states
+    if key + "_pi" not in d.files:
+        raise SystemExit("no (pi,T,E) fixture for %d states" % args.states)
+    pi, T, E = d[key + "_pi"], d[key + "_T"], d[key + "_E"]
+    n_states = pi.shape[0]
+    model_name = "isolation-model" if key.startswith("iso") else "initial-migration-model"
+    workload_kind = args.workload if args.workload != "auto" else ("config2" if world == 1 else "config4-slice")
+
+    from imcoalhmm_amd.dist import shard_indices, slice_bounds
+    split = world > 1 and args.split_file
+    if split:
+        chunks_per_rank, cols = 1, args.columns or 100_000_000
+        workload = "%d states, ONE %d-column synthetic alignment cut into %d contiguous slices (BASELINE config[%d] across GPUs)" % (
+            n_states, cols, world, 1 if key.startswith("iso") else 2)
+        seeds = [20240001]
+    elif workload_kind == "config2":
+        chunks_per_rank, cols = args.chunks or 1, args.columns or 100_000_000
+        workload = "%s %d states, %d x %d-column synthetic pairwise alignment (BASELINE config[%d])" % (
+            model_name, n_states, chunks_per_rank, cols, 1 if key.startswith("iso") else 2)
+        seeds = [20240001 + (1 if not key.startswith("iso") else 0) + k for k in range(chunks_per_rank)]
+        if world > 1:
+            raise SystemExit("--workload config2 is a single-GPU workload (use --split-file to cut one alignment over ranks)")
+    else:
+        chunks_per_rank, cols = args.chunks or 32, args.columns or 10_000_000
+        workload = "%s %d states, %d x %d-column synthetic chunks sharded over %d GPU%s (BASELINE config[3] slice)" % (
+            model_name, n_states, chunks_per_rank * world, cols, world, "" if world == 1 else "s")
+        seeds = [20240100 + i for i in shard_indices(chunks_per_rank * world, rank, world)]
+    lo, hi = slice_bounds(cols, rank, world) if split else (0, cols)
+
+    # ---- synthetic data: everything this process will need, generated before the GPU is touched ----
+    t0 = time.time()
+    requests = [("main%d" % i, key, cols, sd) for i, sd in enumerate(seeds)]
+    extras = world == 1 and not args.no_extra and args.batch == 1 and not args.fixture and workload_kind == "config2" \
+        and not args.no_compress and args.mode < 0 and n_states == 20 and not args.columns and not args.chunks
+    if extras:
+        requests += [("c3", "im150_t0", 100_000_000, 20240002)]
+        requests += [("c4_%d" % i, "iso20_t0", 10_000_000, 20240100 + i) for i in range(32)]
+        requests += [("c5_%d" % i, "im150_t0", 1_000_000, 20240600 + i) for i in range(32)]
+    data = generate(requests)
+    t_gen = time.time() - t0
 
     import torch
     import torch.distributed as dist
-    from imcoalhmm_amd import Forwarder, _capi, synth
-    from imcoalhmm_amd.dist import DistributedLikelihood, SplitAlignmentLikelihood, shard_indices, slice_bounds
+    from imcoalhmm_amd import Forwarder, _capi
+    from imcoalhmm_amd.dist import DistributedLikelihood, SplitAlignmentLikelihood
 
     dev_index = 0 if args.rehearse_on_one_gpu else local_rank
     torch.cuda.set_device(dev_index)
@@ -71,53 +199,22 @@ def main():
     lib = _capi.lib()                       # raises if the HIP library is missing (no fallback)
     _capi.check(lib.imc_set_device(dev_index))
     _capi.check(lib.imc_set_compression(args.mode if args.mode >= 0 else (0 if args.no_compress else 1)))
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if args.rehearse_on_one_gpu else "nccl"
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    # ---- workload -------------------------------------------------------------------------------
-    d = np.load(os.path.join(REPO, "tests", "golden", "hmm_params.npz"))
-    key = args.fixture or "iso%d_t0" % args.states
-    if key + "_pi" not in d.files:
-        raise SystemExit("no (pi,T,E) fixture for %d states" % args.states)
-    pi, T, E = d[key + "_pi"], d[key + "_T"], d[key + "_E"]
-    n_states = pi.shape[0]
-    if world == 1:
-        chunks_per_rank = args.chunks or 1
-        cols = args.columns or 100_000_000
-        workload = "%s %d states, %d x %d-column synthetic pairwise alignment (BASELINE config[%d])" % (
-            "isolation-model" if key.startswith("iso") else "initial-migration-model", n_states, chunks_per_rank, cols,
-            1 if key.startswith("iso") else 2)
-        seeds = [20240001 + k for k in range(chunks_per_rank)]
-    elif args.split_file:
-        chunks_per_rank = 1
-        cols = args.columns or 100_000_000
-        workload = "%d states, ONE %d-column synthetic alignment cut into %d contiguous slices (BASELINE config[%d] across GPUs)" % (
-            n_states, cols, world, 1 if key.startswith("iso") else 2)
-        seeds = [20240001]
-    else:
-        chunks_per_rank = args.chunks or 32
-        cols = args.columns or 10_000_000
-        workload = "isolation-model %d states, %d x %d-column synthetic chunks sharded over %d GPUs (BASELINE config[3] slice)" % (
-            n_states, chunks_per_rank * world, cols, world)
-        seeds = [20240100 + i for i in shard_indices(chunks_per_rank * world, rank, world)]
-    split = world > 1 and args.split_file
-    lo, hi = slice_bounds(cols, rank, world) if split else (0, cols)
-
     t0 = time.time()
     forwarders = []
     first_chunk = None
-    for sd in seeds:
-        # generated in 1e7-column pieces to bound host memory
-        parts = [synth.sample_alignment(pi, T, E, min(10_000_000, cols - off), seed=sd * 1000 + k)
-                 for k, off in enumerate(range(0, cols, 10_000_000)) if off < hi and off + 10_000_000 > lo]
-        obs = parts[0] if len(parts) == 1 else np.concatenate(parts)
+    for i in range(len(seeds)):
+        obs = data.pop("main%d" % i)
         if split:            # this rank's contiguous slice of the one alignment
-            first_piece = (lo // 10_000_000) * 10_000_000
-            obs = obs[lo - first_piece:hi - first_piece]
+            obs = obs[lo:hi]
         if first_chunk is None:
             first_chunk = obs
         forwarders.append(Forwarder.from_array(obs, 3))
@@ -138,22 +235,7 @@ def main():
 
     model_build_ms = None
     if args.batch > 1:
-        # B proposals per step (BASELINE config[4] shape): log-normal random-walk proposals around the
-        # fixture's theta (sd 0.1 in log space, mcmc.py:25,34-35; seed 20240500), turned into (pi, T, E) by
-        # the host-side model layer.  That layer stays on the CPU and outside the timed region (north_star);
-        # its cost per HMM is reported in config.model_build_ms_per_hmm.
-        from imcoalhmm_amd import models
-        model = (models.IsolationModel(n_states) if key.startswith("iso")
-                 else models.IsolationMigrationModel(n_states // 2, n_states - n_states // 2))
-        theta0 = d[key + "_theta"]
-        rng = np.random.default_rng(20240500)
-        thetas = theta0 * np.exp(0.1 * rng.standard_normal((args.batch, len(theta0))))
-        thetas[0] = theta0
-        model.build_batch(thetas[:2])
-        tb = time.perf_counter()
-        pis, Ts, Es = model.build_batch(thetas)
-        model_build_ms = (time.perf_counter() - tb) * 1e3 / args.batch
-        assert np.abs(Ts[0] - T).max() < 1e-12, "model layer disagrees with the reference fixture"
+        pis, Ts, Es, model_build_ms = proposals(d, key, n_states, args.batch, T)
 
     def step():
         if args.batch > 1:
@@ -165,20 +247,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        value = step()
-    lib.imc_profile_enable(1)
-    ms_p, ms_s = ctypes.c_double(), ctypes.c_double()
-    n_p, n_s = ctypes.c_uint64(), ctypes.c_uint64()
-    lib.imc_profile_read(ctypes.byref(ms_p), ctypes.byref(ms_s), ctypes.byref(n_p), ctypes.byref(n_s))  # reset
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        value = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    lib.imc_profile_read(ctypes.byref(ms_p), ctypes.byref(ms_s), ctypes.byref(n_p), ctypes.byref(n_s))
-    lib.imc_profile_enable(0)
+    value, elapsed, k_ms, s_ms = timed_steps(lib, step, args.steps, args.warmup, fence)
     plan = _capi.last_plan()
     rank1_stats = None
     if world == 1 and args.batch == 1:     # one extra synchronous evaluation: the hand-off counters are read back there
@@ -187,7 +256,9 @@ def main():
         rank1_stats = dict(zip(("segments_tested", "collapsed"), _capi.last_rank1()))
     ntok0, alpha0 = forwarders[0].compressed_length(plan["token_alphabet"] or 256) if plan["vector_tokens"] else (len(forwarders[0]), 3)
 
+    ranks = 1
     if world > 1:
+        ranks = dist.get_world_size()
         rdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -200,7 +271,6 @@ def main():
 
     if rank == 0:
         cols_per_s = total_cols * args.batch * args.steps / elapsed
-        k_ms = ms_p.value / max(n_p.value, 1)            # average propagate-kernel duration (HIP events)
         k_s = k_ms * 1e-3
         alg_bytes = float(local_cols) * 1.0               # 1 B of observation stream per column (shared by a batch)
         alg_flops = float(local_cols) * args.batch * (2 * n_states * n_states + 3 * n_states)
@@ -213,24 +283,14 @@ def main():
             # many do is only known at run time -> no executed-flop figure; the tails are an HBM stream instead
             exe_flops = float("nan")
         achieved_gbs = alg_bytes / k_s / 1e9 if k_s > 0 else 0.0
-        # HBM traffic per launch comes from PMC passes (rocprofv3 cannot run inside the bench): the committed
-        # measurement for this kernel / N / column count, if any (profiles/r01_traffic_pmc.json), else null
-        traffic = None
-        try:
-            with open(os.path.join(REPO, "profiles", "r01_traffic_pmc.json")) as fh:
-                rec = json.load(fh).get("%s|%d|%d" % (kernel_name, n_states, local_cols)
-                                        + ("|B%d" % args.batch if args.batch > 1 else ""))
-            if rec and world == 1:
-                traffic = rec["hbm_bytes_per_launch"]
-        except (OSError, ValueError):
-            pass
+        traffic = lookup_traffic(kernel_name, n_states, local_cols, args.batch) if world == 1 else None
         operator_stream = None
         if "k_big_vector" in kernel_name and k_s > 0:
             # the mat-vec chain kernel is bound by streaming one NP x NP operator per chain step from L2 / Infinity Cache
             npad = 16 * ((n_states + 15) // 16)
             op_bytes = float(plan["vector_tokens"]) * npad * npad * 8.0
-            operator_stream = {"bytes_per_launch": op_bytes, "achieved_gbs": op_bytes / k_s / 1e9,
-                               "hbm_side_gbs": (traffic / k_s / 1e9) if traffic else None,
+            operator_stream = {"bytes_per_launch": op_bytes, "memory_side_gbs": op_bytes / k_s / 1e9,
+                               "pmc_fetch_gbs": (traffic / k_s / 1e9) if traffic else None,
                                "ceilings_gbs": {"l2_shared_rows": 16800.0, "infinity_cache": 8600.0, "hbm": 8000.0},
                                "note": "ceilings: MI355X_MICROARCH.md 'Indexed rows' table (chip-wide, measured)"}
         out = {
@@ -238,6 +298,8 @@ def main():
             "value": cols_per_s,
             "unit": "columns/s",
             "n_gpus": n_gpus,
+            "ranks": ranks,
+            "backend": backend,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -252,30 +314,158 @@ def main():
                        "column_segment_len": plan["column_segment_len"], "token_segment_len": plan["token_segment_len"],
                        "compression": "pair dictionary, %d tokens" % plan["token_alphabet"] if plan["vector_tokens"] else "off",
                        "columns_per_token": (len(forwarders[0]) / max(ntok0, 1)) if plan["vector_tokens"] else 1.0,
-                       "setup_s": t_setup, "model_build_ms_per_hmm": model_build_ms, "loglik": value,
+                       "generate_s": t_gen, "setup_s": t_setup, "model_build_ms_per_hmm": model_build_ms, "loglik": value,
                        "rank1_handoff": rank1_stats},
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": kernel_name, "kernel_ms": k_ms, "operator_stream": operator_stream, "stitch_ms": ms_s.value / max(n_s.value, 1),
+                "kernel": kernel_name, "kernel_ms": k_ms, "operator_stream": operator_stream, "stitch_ms": s_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "north_star names the HBM roof, but with 1 B/column the path is fp64-VALU/latency bound; "
-                        "see fp64_valu",
-                "fp64_valu": {
+                "note": "north_star names the HBM roof, but with 1 B/column the path is bound by the fp64 units "
+                        "(v_fma_f64 and v_mfma_f64 share them); see fp64",
+                "fp64": {
                     "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                    "algorithmic_tflops": alg_flops / k_s / 1e12 if k_s > 0 else 0.0,
                     "executed_tflops": None if handoff else (exe_flops / k_s / 1e12 if k_s > 0 else 0.0),
-                    "frac_algorithmic": alg_flops / k_s / 1e12 / FP64_VALU_PEAK_TFLOPS if k_s > 0 else 0.0,
                     "frac_executed": None if handoff else (exe_flops / k_s / 1e12 / FP64_VALU_PEAK_TFLOPS if k_s > 0 else 0.0),
+                    "algorithmic_tflops": alg_flops / k_s / 1e12 if k_s > 0 else 0.0,
+                    "note": "algorithmic = (2N^2+3N) flop per column; with pair compression one executed step covers "
+                            "many columns, so the algorithmic rate is not a fraction of any peak",
                 },
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pi, T, E, first_chunk, args.cpu_sample_columns)
+    if extras:
+        del forwarders, ll
+        ex = extra_configs(lib, d, data, fence)
+        if rank == 0:
+            out["extra_configs"] = ex
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def proposals(d, key, n_states, batch, T_check=None):
+    """B proposals per step (BASELINE config[4] shape): log-normal random-walk proposals around the fixture's theta
+    (sd 0.1 in log space, mcmc.py:25,34-35; seed 20240500), turned into (pi, T, E) by the host-side model layer.  That
+    layer stays on the CPU and outside the timed region (north_star); its cost per HMM is returned in ms."""
+    from imcoalhmm_amd import models
+    model = (models.IsolationModel(n_states) if key.startswith("iso")
+             else models.IsolationMigrationModel(n_states // 2, n_states - n_states // 2))
+    theta0 = d[key + "_theta"]
+    rng = np.random.default_rng(20240500)
+    thetas = theta0 * np.exp(0.1 * rng.standard_normal((batch, len(theta0))))
+    thetas[0] = theta0
+    model.build_batch(thetas[:2])
+    tb = time.perf_counter()
+    pis, Ts, Es = model.build_batch(thetas)
+    ms = (time.perf_counter() - tb) * 1e3 / batch
+    if T_check is not None:
+        assert np.abs(Ts[0] - T_check).max() < 1e-12, "model layer disagrees with the reference fixture"
+    return pis, Ts, Es, ms
+
+
+def lookup_traffic(kernel_name, n_states, local_cols, batch):
+    """HBM bytes per launch from committed PMC passes (rocprofv3 cannot run inside the bench): the measurement for this
+    kernel / N / column count if there is one (profiles/r02_traffic_pmc.json, else round 1's), else None."""
+    k = "%s|%d|%d" % (kernel_name, n_states, local_cols) + ("|B%d" % batch if batch > 1 else "")
+    for name in ("r02_traffic_pmc.json", "r01_traffic_pmc.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as fh:
+                rec = json.load(fh).get(k)
+            if rec:
+                return rec["hbm_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
+    return None
+
+
+def extra_configs(lib, d, data, fence):
+    """The other BASELINE configs at the size one GPU carries, a few steps each, after the headline measurement:
+    config[2] (150 states, 1 x 1e8 columns), the per-GPU slice of config[3] (20 states, 32 x 1e7) and of config[4]
+    (150 states, 64 proposals x 32 x 1e6).  `value` is columns/s (column-evaluations/s for the batch)."""
+    from imcoalhmm_amd import Forwarder, _capi
+    from imcoalhmm_amd.hmm import forward_chunks, forward_chunks_batch
+    res = []
+
+    def run(workload, fw, fn, cols, batch, steps, warmup):
+        value, elapsed, k_ms, s_ms = timed_steps(lib, fn, steps, warmup, fence)
+        plan = _capi.last_plan()
+        res.append({"workload": workload, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+                    "value": cols * batch * steps / elapsed, "unit": "columns/s" if batch == 1 else "column-evaluations/s",
+                    "kernel": plan["kernels"], "kernel_ms": k_ms, "stitch_ms": s_ms, "loglik": value})
+
+    # config[2]: ~150 states (IsolationMigrationModel(75, 75)), one 1e8-column alignment
+    pi, T, E = d["im150_t0_pi"], d["im150_t0_T"], d["im150_t0_E"]
+    t0 = time.time()
+    fw = [Forwarder.from_array(data.pop("c3"), 3)]
+    h = [f.handle for f in fw]
+    run("initial-migration-model 150 states, 1 x 100000000-column synthetic alignment (BASELINE config[2])", fw,
+        lambda: forward_chunks(h, pi, T, E), 1e8, 1, 3, 2)
+    res[-1]["setup_s"] = time.time() - t0
+    res[-1]["rank1_handoff"] = dict(zip(("segments_tested", "collapsed"), _capi.last_rank1()))
+    del fw, h
+    # config[3] slice: 20 states, 32 x 1e7 columns (what one of 8 GPUs holds of the 256 chunks)
+    pi20, T20, E20 = d["iso20_t0_pi"], d["iso20_t0_T"], d["iso20_t0_E"]
+    t0 = time.time()
+    fw = [Forwarder.from_array(data.pop("c4_%d" % i), 3) for i in range(32)]
+    h = [f.handle for f in fw]
+    run("isolation-model 20 states, 32 x 10000000-column synthetic chunks (per-GPU slice of BASELINE config[3])", fw,
+        lambda: forward_chunks(h, pi20, T20, E20), 3.2e8, 1, 5, 2)
+    res[-1]["setup_s"] = time.time() - t0
+    del fw, h
+    # config[4] slice: 150 states, 64 proposals per step x 32 x 1e6 columns
+    pis, Ts, Es, ms = proposals(d, "im150_t0", 150, 64)
+    t0 = time.time()
+    fw = [Forwarder.from_array(data.pop("c5_%d" % i), 3) for i in range(32)]
+    h = [f.handle for f in fw]
+    run("initial-migration-model 150 states, 64 proposals/step x 32 x 1000000-column chunks (per-GPU slice of BASELINE config[4])",
+        fw, lambda: float(forward_chunks_batch(h, pis, Ts, Es)[0]), 3.2e7, 64, 2, 1)
+    res[-1]["setup_s"] = time.time() - t0
+    res[-1]["model_build_ms_per_hmm"] = ms
+    del fw, h
+    return res
+
+
+def rehearse_cpu(args, rank, world):
+    """Launcher / sharding / reduction rehearsal with no GPU anywhere (tests): every rank owns its config-4 shard of
+    chunk ids, its "partial log-likelihood" is a stand-in computed on the host, the reduction is the real
+    DistributedLikelihood path over gloo.  The printed line is marked invalid and carries no throughput claim."""
+    import torch
+    import torch.distributed as dist
+    from imcoalhmm_amd.dist import DistributedLikelihood, shard_indices
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    chunks_per_rank = args.chunks or 4
+    mine = shard_indices(chunks_per_rank * world, rank, world)
+
+    class FixedModel(object):
+        def valid_parameters(self, p):
+            return True
+
+        def build_hidden_markov_model(self, p):
+            return np.ones(2) / 2, np.eye(2), np.ones((2, 3)) / 3
+
+    def local_eval(pis, Ts, Es):
+        return torch.tensor([-float(sum(1000 + i for i in mine))] * pis.shape[0], dtype=torch.float64)
+
+    ll = DistributedLikelihood(FixedModel(), [], local_eval=local_eval)
+    value = ll(np.array([1.0]))
+    want = -float(sum(1000 + i for i in range(chunks_per_rank * world)))
+    ranks = dist.get_world_size() if world > 1 else 1
+    if rank == 0:
+        print(json.dumps({"metric": "launcher rehearsal (no GPU, INVALID as a measurement)", "value": 0.0, "unit": "columns/s",
+                          "n_gpus": args.gpus, "ranks": ranks, "backend": "gloo" if world > 1 else None,
+                          "steps": args.steps, "warmup": args.warmup, "valid": False,
+                          "config": {"workload": "rehearsal", "chunks": chunks_per_rank * world, "loglik": value,
+                                     "loglik_expected": want}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if value == want else 1
 
 
 def cpu_baseline(pi, T, E, obs, cols_per_thread):
@@ -306,12 +496,13 @@ def cpu_baseline(pi, T, E, obs, cols_per_thread):
     total = float(n * cores)
     best = min(t_zip, t_plain)
     return {"value": total / best, "unit": "columns/s", "cores": cores, "kind": "port",
-            "sample": "%d threads x %d columns of the same synthetic alignment (%.0f%% of it), each slice its own chunk, "
-                      "repeated for ~10 s; zipHMM-style compressed forward %.3g col/s (compression ratio %.1fx), textbook "
-                      "scaled forward %.3g col/s; CPU restatement of the ziphmm forward, ziphmm itself is not installable "
-                      "offline" % (cores, n, 100.0 * n * cores / obs.size, total / t_zip, n / max(zips[0].length, 1),
-                                   total / t_plain)}
+            "sample": "%d threads x %d columns of the same synthetic alignment (%.0f%% of it), each slice its own chunk "
+                      "(so NOT the same computation as the GPU's single chain - a stated baseline, not a like-for-like "
+                      "ratio), repeated for ~10 s; zipHMM-style compressed forward %.3g col/s (compression ratio %.1fx), "
+                      "textbook scaled forward %.3g col/s; CPU restatement of the ziphmm forward, ziphmm itself is not "
+                      "installable offline" % (cores, n, 100.0 * n * cores / obs.size, total / t_zip,
+                                               n / max(zips[0].length, 1), total / t_plain)}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -42,6 +42,7 @@
 #include "kernels_zip.hpp"
 #include "kernels_big.hpp"
 #include "kernels_zip2.hpp"
+#include "kernels_zip3.hpp"
 #include "pair_dict.hpp"
 #include "obs_io.hpp"
 
@@ -73,8 +74,12 @@ constexpr size_t DICT_WIDE_MIN_COUNT = 6;          // ... in which a pair must o
 constexpr size_t CTAB_BUDGET = (size_t)24 << 30;   // largest operator table (all parameter sets) a plan may allocate
 constexpr size_t R1_MIN_SEGLEN = 1024;             // rank-one hand-off: segments at least this long (stream elements) ...
 constexpr size_t R1_MIN_HEAD = 256;                // ... run at least this many on the GEMM chain before the test
-constexpr double R1_HEAD_COLUMNS = 65536.0;        // ... and about this many alignment columns (first call of a plan)
-constexpr double R1_HEAD_MIN_COLUMNS = 8192.0;     // ... never fewer than this however well the tests go
+constexpr double R1_HEAD_COLUMNS = 65536.0;        // planner's estimate of the columns a head needs before it collapses
+constexpr double R1_HEAD_MIN_COLUMNS = 8192.0;     // first checkpoint of the hand-off test, in alignment columns
+constexpr int R1_MAX_ROUNDS = 20;                  // checkpoints per evaluation (each ~1.25x the previous one)
+
+hipError_t dev_alloc(void **p, size_t bytes);
+void dev_free(void *p);
 
 struct DictDev {                                   // one trained dictionary + its device copy
     imc::PairDict dict;
@@ -85,7 +90,7 @@ struct DictDev {                                   // one trained dictionary + i
     pid_t pid = 0;
     ~DictDev()
     {
-        if (pid == getpid()) { (void)hipFree(d_left); (void)hipFree(d_right); (void)hipFree(d_order); }
+        if (pid == getpid()) { dev_free(d_left); dev_free(d_right); dev_free(d_order); }
     }
 };
 
@@ -103,6 +108,9 @@ struct Ctx {
     int kernel_pref = 0;      // 0 = automatic, 1 = vector kernels (k_propagate / k_zpropagate), 2 = blocked (k_zpropagate2)
     bool profile = false;
     bool rank1_handoff = true; // IMC_RANK1=0 switches the rank-one hand-off of the GEMM chain off (A/B measurements)
+    int blocked_variant = 3;  // register-blocked kernel: 3 = k_zpropagate3 (fp64 MFMA 4x4x4), 2 = k_zpropagate2 (DPP, VALU);
+                              // IMC_BLOCKED=2 pins the VALU variant (A/B measurements, tests)
+    bool guard = false;       // IMC_GUARD=1: every device buffer ends flush against an unmapped guard range (dev_alloc)
     bool use_graphs = false;  // IMC_GRAPH=1: replay each plan's launch sequence as a hipGraph (measured: no gain, the
                               // per-evaluation latency is kernel time + kernel boundaries, not host launch cost)
     std::vector<Ev3> events;
@@ -119,13 +127,13 @@ int ensure_ctx()
 {
     const pid_t me = getpid();
     if (g.ready && g.pid == me) return IMC_OK;
-    if (g.ready && g.pid != me) {
-        // forked child: the parent's HIP state is not usable here; start over (handles leak, by design)
-        g.ready = false;
-        g.stream = nullptr;
-        g.events.clear();
-        g.dicts.clear();
-    }
+    if (g.ready && g.pid != me)
+        // A forked child of a process that had already used the GPU: the parent's HIP state (context, streams, every
+        // device pointer held by cached plans and dictionaries) is not usable here and HIP cannot be re-initialised
+        // after fork().  Refuse instead of guessing; nothing of the parent's is freed or touched.  Children that
+        // build their own Forwarders (mcmc.py:112-121) must be forked BEFORE the parent's first library call.
+        return fail(IMC_ERR_HIP, "libimcoal_fwd was initialised in the parent process before fork(): fork the chain "
+                                 "processes before the first imc_* call of the parent, or use the spawn start method");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(IMC_ERR_NODEVICE, "no HIP device available (libimcoal_fwd has no CPU fallback)");
@@ -143,10 +151,67 @@ int ensure_ctx()
     g.cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     g.use_graphs = std::getenv("IMC_GRAPH") != nullptr;
+    if (const char *gd = std::getenv("IMC_GUARD")) g.guard = std::atoi(gd) != 0;
+    if (const char *bv = std::getenv("IMC_BLOCKED")) g.blocked_variant = std::atoi(bv) == 2 ? 2 : 3;
     if (const char *r1 = std::getenv("IMC_RANK1")) g.rank1_handoff = std::atoi(r1) != 0;
     g.pid = me;
     g.ready = true;
     return IMC_OK;
+}
+
+// ---- device memory -----------------------------------------------------------------------------------
+// Every device buffer of the library comes from here.  Normal mode: hipMalloc / hipFree.  Guard mode (IMC_GUARD=1, a
+// test facility): each buffer is its own virtual-memory reservation with NO mapping behind its last 16-byte unit, so
+// a kernel that reads or writes even one vector load past a buffer's declared size faults deterministically instead of
+// silently touching whatever the allocator happened to place next (tests/test_gpu_guard.py runs the create / free /
+// compression-flip / create sequence of round 1's unexplained fault this way).
+struct GuardRec { hipDeviceptr_t va; size_t va_size; hipMemGenericAllocationHandle_t handle; hipDeviceptr_t map; size_t map_size; };
+std::map<void *, GuardRec> g_guard;
+
+hipError_t dev_alloc(void **p, size_t bytes)
+{
+    bytes = std::max<size_t>(bytes, 16);
+    if (!g.guard) return hipMalloc(p, bytes);
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = g.device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess || gran == 0) return e != hipSuccess ? e : hipErrorUnknown;
+    GuardRec r{};
+    r.map_size = (bytes + gran - 1) / gran * gran;
+    r.va_size = r.map_size + 2 * gran;              // one unmapped granule before, one after
+    e = hipMemAddressReserve(&r.va, r.va_size, gran, nullptr, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemCreate(&r.handle, r.map_size, &prop, 0);
+    if (e != hipSuccess) { (void)hipMemAddressFree(r.va, r.va_size); return e; }
+    r.map = (hipDeviceptr_t)((char *)r.va + gran);
+    e = hipMemMap(r.map, r.map_size, 0, r.handle, 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc ad{};
+        ad.location = prop.location;
+        ad.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(r.map, r.map_size, &ad, 1);
+        if (e != hipSuccess) (void)hipMemUnmap(r.map, r.map_size);
+    }
+    if (e != hipSuccess) { (void)hipMemRelease(r.handle); (void)hipMemAddressFree(r.va, r.va_size); return e; }
+    void *user = (char *)r.map + (r.map_size - (bytes + 15) / 16 * 16);   // the buffer's end is the mapping's end
+    g_guard[user] = r;
+    *p = user;
+    return hipSuccess;
+}
+
+void dev_free(void *p)
+{
+    if (!p) return;
+    auto it = g_guard.find(p);
+    if (it == g_guard.end()) { (void)hipFree(p); return; }
+    (void)hipDeviceSynchronize();
+    (void)hipMemUnmap(it->second.map, it->second.map_size);
+    (void)hipMemRelease(it->second.handle);
+    (void)hipMemAddressFree(it->second.va, it->second.va_size);
+    g_guard.erase(it);
 }
 
 }  // namespace
@@ -172,7 +237,7 @@ constexpr size_t OBS_PAD = 256;
 hipError_t upload_padded(const uint8_t *host, size_t n, uint8_t **dptr)
 {
     const size_t bytes = ((n + OBS_PAD - 1) / OBS_PAD) * OBS_PAD + OBS_PAD;
-    hipError_t e = hipMalloc((void **)dptr, bytes);
+    hipError_t e = dev_alloc((void **)dptr, bytes);
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(*dptr, 0, bytes, g.stream);
     if (e == hipSuccess && n) e = hipMemcpyAsync(*dptr, host, n, hipMemcpyHostToDevice, g.stream);
@@ -182,17 +247,75 @@ hipError_t upload_padded(const uint8_t *host, size_t n, uint8_t **dptr)
 
 void obs_release(imc_obs *o)
 {
-    (void)hipFree(o->d_sym);
+    dev_free(o->d_sym);
     for (int l = 0; l < imc::kNumLevels; ++l) {
         bool alias = false;
         for (int m = 0; m < l; ++m) alias |= (o->d_tok[m] == o->d_tok[l]);
-        if (o->d_tok[l] && !alias) (void)hipFree(o->d_tok[l]);
+        if (o->d_tok[l] && !alias) dev_free(o->d_tok[l]);
     }
 }
 
+// Build a chunk from validated host symbols.  Called WITHOUT g_mu: the O(L) host work (dictionary training, the
+// multi-level encoding: ~1.4 s at 1e8 columns) runs unlocked so that other threads keep evaluating; the lock is
+// taken only to read / publish the shared dictionary and for the HIP calls on the library's stream.
 int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
 {
+    std::shared_ptr<DictDev> dd;
+    bool want_zip = false, train = false;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = ensure_ctx()) return rc;
+        // ---- compression (the preprocess_raw_observations analogue, hmm.py:16) ----
+        want_zip = g.compression && L >= ZIP_MIN_COLUMNS && nsym <= 64;
+        if (want_zip) {
+            auto it = g.dicts.find(nsym);
+            if (it != g.dicts.end()) dd = it->second;
+            else train = L >= DICT_TRAIN_MIN;
+        }
+    }
+    if (train) {                                        // host only, unlocked
+        auto nd = std::make_shared<DictDev>();
+        const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
+        imc::train_dict(nd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64);
+        if (nd->dict.alphabet >= imc::kByteAlphabet) {   // 16-bit tokens: rounds over the whole chunk's byte-level stream
+            const size_t cols = std::min(L, DICT_WIDE_TRAIN_TOKENS * 96);   // a byte-level token covers ~60-100 columns
+            const std::vector<uint8_t> lvl256 = imc::encode_bytes(nd->dict, host, cols, nullptr);
+            const size_t nt = std::min(lvl256.size() - 1, DICT_WIDE_TRAIN_TOKENS);
+            imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), DICT_WIDE_MIN_COUNT);
+        }
+        nd->depth.assign(nd->dict.alphabet, 0);
+        for (int z = nsym; z < nd->dict.alphabet; ++z)
+            nd->depth[z] = 1 + std::max(nd->depth[nd->dict.left[z]], nd->depth[nd->dict.right[z]]);
+        for (int z = nsym; z < nd->dict.alphabet; ++z) nd->order.push_back((uint16_t)z);
+        std::stable_sort(nd->order.begin(), nd->order.end(),
+                         [&](uint16_t x, uint16_t y) { return nd->depth[x] < nd->depth[y]; });
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g.dicts.find(nsym);
+        if (it != g.dicts.end()) dd = it->second;       // another thread published one meanwhile: use that
+        else {
+            HIP_TRY(hipSetDevice(g.device));
+            nd->pid = g.pid;
+            nd->dict.id = g.next_dict_id++;
+            const size_t abytes = (size_t)nd->dict.alphabet * sizeof(uint16_t);
+            hipError_t e2 = dev_alloc((void **)&nd->d_left, abytes);
+            if (e2 == hipSuccess) e2 = dev_alloc((void **)&nd->d_right, abytes);
+            if (e2 == hipSuccess) e2 = hipMemcpy(nd->d_left, nd->dict.left.data(), abytes, hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = hipMemcpy(nd->d_right, nd->dict.right.data(), abytes, hipMemcpyHostToDevice);
+            if (e2 == hipSuccess) e2 = dev_alloc((void **)&nd->d_order, std::max<size_t>(abytes, 16));
+            if (e2 == hipSuccess && !nd->order.empty())
+                e2 = hipMemcpy(nd->d_order, nd->order.data(), nd->order.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+            if (e2 != hipSuccess) return fail(IMC_ERR_HIP, std::string("dictionary upload: ") + hipGetErrorString(e2));
+            g.dicts[nsym] = nd;
+            dd = nd;
+        }
+    }
+    imc::EncodedLevels enc;
+    const bool zipped = dd && dd->dict.alphabet > nsym;
+    if (zipped) imc::encode_levels(dd->dict, host, L, enc);   // host only, unlocked (a published dictionary is immutable)
+
+    std::lock_guard<std::mutex> lk(g_mu);
     if (int rc = ensure_ctx()) return rc;
+    HIP_TRY(hipSetDevice(g.device));
     auto *o = new (std::nothrow) imc_obs();
     if (!o) return fail(IMC_ERR_OOM, "host allocation failed");
     o->id = g.next_obs_id++;
@@ -208,63 +331,22 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
         return fail(e == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
                     std::string("observation upload: ") + hipGetErrorString(e));
     }
-    // ---- compression (the preprocess_raw_observations analogue, hmm.py:16) ----
-    if (g.compression && L >= ZIP_MIN_COLUMNS && nsym <= 64) {
-        std::shared_ptr<DictDev> dd;
-        auto it = g.dicts.find(nsym);
-        if (it != g.dicts.end()) dd = it->second;
-        else if (L >= DICT_TRAIN_MIN) {
-            dd = std::make_shared<DictDev>();
-            dd->pid = g.pid;
-            const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
-            imc::train_dict(dd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64);
-            if (dd->dict.alphabet >= imc::kByteAlphabet) {   // 16-bit tokens: rounds over the whole chunk's byte-level stream
-                const size_t cols = std::min(L, DICT_WIDE_TRAIN_TOKENS * 96);   // a byte-level token covers ~60-100 columns
-                const std::vector<uint8_t> lvl256 = imc::encode_bytes(dd->dict, host, cols, nullptr);
-                const size_t nt = std::min(lvl256.size() - 1, DICT_WIDE_TRAIN_TOKENS);
-                imc::train_dict_wide(dd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), DICT_WIDE_MIN_COUNT);
-            }
-            dd->dict.id = g.next_dict_id++;
-            const size_t abytes = (size_t)dd->dict.alphabet * sizeof(uint16_t);
-            hipError_t e2 = hipMalloc((void **)&dd->d_left, abytes);
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&dd->d_right, abytes);
-            if (e2 == hipSuccess) e2 = hipMemcpy(dd->d_left, dd->dict.left.data(), abytes, hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = hipMemcpy(dd->d_right, dd->dict.right.data(), abytes, hipMemcpyHostToDevice);
-            dd->depth.assign(dd->dict.alphabet, 0);
-            for (int z = nsym; z < dd->dict.alphabet; ++z)
-                dd->depth[z] = 1 + std::max(dd->depth[dd->dict.left[z]], dd->depth[dd->dict.right[z]]);
-            for (int z = nsym; z < dd->dict.alphabet; ++z) dd->order.push_back((uint16_t)z);
-            std::stable_sort(dd->order.begin(), dd->order.end(),
-                             [&](uint16_t x, uint16_t y) { return dd->depth[x] < dd->depth[y]; });
-            if (e2 == hipSuccess) e2 = hipMalloc((void **)&dd->d_order, std::max<size_t>(abytes, 16));
-            if (e2 == hipSuccess && !dd->order.empty())
-                e2 = hipMemcpy(dd->d_order, dd->order.data(), dd->order.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-            if (e2 != hipSuccess) {
+    if (zipped) {
+        o->dict = dd;
+        for (int l = 0; l < imc::kNumLevels; ++l) {
+            o->alphabet[l] = enc.alphabet[l];
+            o->ntok[l] = enc.length[l];
+            o->wide[l] = enc.is_wide[l];
+            if (l > 0 && enc.alphabet[l] == enc.alphabet[l - 1]) { o->d_tok[l] = o->d_tok[l - 1]; o->wide[l] = o->wide[l - 1]; continue; }
+            if (enc.alphabet[l] <= nsym) { o->d_tok[l] = nullptr; continue; }   // raw stream: use d_sym
+            hipError_t e3 = enc.is_wide[l]
+                ? upload_padded(reinterpret_cast<const uint8_t *>(enc.wide[l].data()), enc.length[l] * sizeof(imc::tok_t), &o->d_tok[l])
+                : upload_padded(enc.bytes[l].data(), enc.length[l], &o->d_tok[l]);
+            if (e3 != hipSuccess) {
                 obs_release(o);
                 delete o;
-                return fail(IMC_ERR_HIP, std::string("dictionary upload: ") + hipGetErrorString(e2));
-            }
-            g.dicts[nsym] = dd;
-        }
-        if (dd && dd->dict.alphabet > nsym) {
-            imc::EncodedLevels enc;
-            imc::encode_levels(dd->dict, host, L, enc);
-            o->dict = dd;
-            for (int l = 0; l < imc::kNumLevels; ++l) {
-                o->alphabet[l] = enc.alphabet[l];
-                o->ntok[l] = enc.length[l];
-                o->wide[l] = enc.is_wide[l];
-                if (l > 0 && enc.alphabet[l] == enc.alphabet[l - 1]) { o->d_tok[l] = o->d_tok[l - 1]; o->wide[l] = o->wide[l - 1]; continue; }
-                if (enc.alphabet[l] <= nsym) { o->d_tok[l] = nullptr; continue; }   // raw stream: use d_sym
-                hipError_t e3 = enc.is_wide[l]
-                    ? upload_padded(reinterpret_cast<const uint8_t *>(enc.wide[l].data()), enc.length[l] * sizeof(imc::tok_t), &o->d_tok[l])
-                    : upload_padded(enc.bytes[l].data(), enc.length[l], &o->d_tok[l]);
-                if (e3 != hipSuccess) {
-                    obs_release(o);
-                    delete o;
-                    return fail(e3 == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
-                                std::string("token stream upload: ") + hipGetErrorString(e3));
-                }
+                return fail(e3 == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
+                            std::string("token stream upload: ") + hipGetErrorString(e3));
             }
         }
     }
@@ -297,6 +379,12 @@ struct KernelChoice {
     size_t (*zip2_lds)(int);
     bool zip2_attr_set;
     bool plain_attr_set = false;
+    void (*zip3)(BigArgs) = nullptr;   // ... its fp64-MFMA form (same launch geometry and block list)
+    size_t (*zip3_lds)(int) = nullptr;
+    bool zip3_attr_set = false;
+    // the blocked kernel in use (g.blocked_variant) and its LDS need for an alphabet of A tokens
+    bool use3() const;
+    size_t blocked_lds(int A) const { return use3() ? zip3_lds(A) : zip2_lds(A); }
 };
 
 template <int R, int G, int MW>
@@ -308,6 +396,8 @@ KernelChoice make_kc()
     if constexpr (NP % 4 == 0 && NP <= 24) {
         k.zip2 = k_zpropagate2<NP / 4>;
         k.zip2_lds = &Zip2Geom<NP / 4>::lds_bytes;
+        k.zip3 = k_zpropagate3<NP / 4>;
+        k.zip3_lds = &Zip3Geom<NP / 4>::lds_bytes;
     }
     return k;
 }
@@ -324,6 +414,8 @@ KernelChoice make_big()
                         k_big_table_level<NT>, prop, dealt ? BS_WAVES : NT, k_big_vector<NT, false>, k_big_vector<NT, true>, BigVec<NT>::WAVES, NSLAB,
                         BigSlab<NT, NSLAB>::bytes, nullptr, nullptr, false};
 }
+
+bool KernelChoice::use3() const { return zip3 && g.blocked_variant == 3; }
 
 KernelChoice kChoices[] = {
     make_kc<4, 1, 2>(), make_kc<4, 2, 2>(), make_kc<4, 3, 2>(), make_kc<4, 4, 2>(), make_kc<4, 5, 2>(),
@@ -350,8 +442,8 @@ KernelChoice *choose_kernel(int N, bool prefer_gemm)
 
 void reset_kernel_attributes()
 {
-    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = k.plain_attr_set = false;
-    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = k.plain_attr_set = false;
+    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.plain_attr_set = false;
+    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.plain_attr_set = false;
 }
 
 // ---- launch plan ----------------------------------------------------------------------------------
@@ -368,17 +460,17 @@ struct Group {             // one propagate launch
     Z2Block *d_blocks = nullptr;
     double *d_Ctab = nullptr;
     int *d_cex = nullptr;
-    // rank-one hand-off (GEMM chain only): operator segments run head_len tokens on the GEMM chain, are tested by
-    // k_rank1_check, and those that collapsed to u alpha^T finish on the mat-vec chain
+    // rank-one hand-off (GEMM chain only): operator segments run on the GEMM chain in rounds that end at the
+    // checkpoints (token counts); after each round k_rank1_check tests the segments still on the chain, and those
+    // that collapsed to u alpha^T finish on the mat-vec chain from that checkpoint.  The schedule is fixed per plan,
+    // the decision per segment comes from the data of the evaluation: nothing is carried from call to call.
     bool rank1 = false;
-    int head_len = 0;
+    int head_len = 0;                         // the planner's estimate (cost model only)
+    std::vector<int> checkpoints;
     std::vector<BigBlock> tail_blocks;        // one entry per segment (operator tails and first segments)
     std::vector<std::pair<uint32_t, uint32_t>> r1_segs;   // (plan-wide id, length) of the operator segments
-    int head_min = 0, head_max = 0;           // the head adapts between these from call to call (collect_rank1_stats)
-    bool head_frozen = false;                 // a test failed once: no further shortening
-    int head_good = 0;                        // last head length at which every test passed
     BigBlock *d_tail_blocks = nullptr;
-    int *d_r1flag = nullptr;
+    int *d_r1flag = nullptr, *d_r1at = nullptr;
     double *d_r1u = nullptr, *d_r1alpha = nullptr;
     bool zip = false;
     int level = -1, A = 0;
@@ -399,8 +491,8 @@ struct Level {             // one level of the stitch hierarchy (level 0 = propa
     int *d_EX = nullptr, *d_EMAX = nullptr;
     void release()
     {
-        (void)hipFree(d_vec0); (void)hipFree(d_first); (void)hipFree(d_chains);
-        (void)hipFree(d_P); (void)hipFree(d_EX); (void)hipFree(d_EMAX);
+        dev_free(d_vec0); dev_free(d_first); dev_free(d_chains);
+        dev_free(d_P); dev_free(d_EX); dev_free(d_EMAX);
     }
 };
 
@@ -417,7 +509,13 @@ struct Plan {
     int32_t *d_final_vec = nullptr;  // per chunk: vector index in the last level, -1 for an empty chunk
     uint64_t chain_steps = 0;        // serial depth of the stitch (sum over levels of the longest chain)
     double *d_params = nullptr, *d_out = nullptr;
-    double *h_params = nullptr, *h_out = nullptr;   // pinned
+    // pinned staging of the caller's parameters: two slots used alternately, each guarded by an event recorded behind
+    // its upload, so a call only waits when the upload issued two calls earlier is still pending
+    double *h_params[2] = {nullptr, nullptr};
+    hipEvent_t ev_params[2] = {nullptr, nullptr};
+    bool ev_used[2] = {false, false};
+    int slot = 0;
+    double *h_out = nullptr;                        // pinned
     double *h_out_dev = nullptr;                    // device-visible alias of h_out (k_finish writes results straight to the host)
     hipGraphExec_t graph = nullptr;                 // captured enqueue(), replayed by run_batch
     uint64_t calls = 0;
@@ -426,11 +524,12 @@ struct Plan {
     void release()
     {
         if (graph) (void)hipGraphExecDestroy(graph);
-        (void)hipFree(d_segs); (void)hipFree(d_vecs); (void)hipFree(d_final_vec);
+        dev_free(d_segs); dev_free(d_vecs); dev_free(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { (void)hipFree(gr.d_seg_ids); (void)hipFree(gr.d_seg_out); (void)hipFree(gr.d_blocks); (void)hipFree(gr.d_big_blocks); (void)hipFree(gr.d_Ctab); (void)hipFree(gr.d_cex); (void)hipFree(gr.d_tail_blocks); (void)hipFree(gr.d_r1flag); (void)hipFree(gr.d_r1u); (void)hipFree(gr.d_r1alpha); }
-        (void)hipFree(d_params); (void)hipFree(d_out);
-        (void)hipHostFree(h_params); (void)hipHostFree(h_out);
+        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
+        dev_free(d_params); dev_free(d_out);
+        for (int k = 0; k < 2; ++k) { (void)hipHostFree(h_params[k]); if (ev_params[k]) (void)hipEventDestroy(ev_params[k]); }
+        (void)hipHostFree(h_out);
     }
 };
 
@@ -546,8 +645,8 @@ struct PlanBuilder {
         int a_max = 0;   // largest alphabet whose operator table fits LDS for this N (no limit on the large-N path)
         if (big) a_max = imc::kMaxAlphabet;
         else
-            for (int A = 1; A <= imc::kMaxAlphabet; ++A)
-                if (kc->zip_lds(A) <= LDS_BUDGET || (kc->zip2 && g.kernel_pref != 1 && kc->zip2_lds(A) <= LDS_BUDGET)) a_max = A;
+            for (int A = 1; A <= imc::kByteAlphabet; ++A)   // (the LDS-table kernels read byte streams only)
+                if (kc->zip_lds(A) <= LDS_BUDGET || (kc->zip2 && g.kernel_pref != 1 && kc->blocked_lds(A) <= LDS_BUDGET)) a_max = A;
         // One dictionary level per dictionary: the deepest level is not always the best - every workgroup rebuilds
         // the operator table per evaluation ((A - S) dependent small products), which dominates on short inputs.
         // Estimate: table build + main loop with all 16-lane rows of the machine busy.
@@ -669,12 +768,14 @@ struct PlanBuilder {
                 gr.seglen = seg_vec;
                 // ... or the register-blocked kernel (one operator per 16-lane row): fill every row of the machine
                 // once; first segments waste 1 - 1/N of their row, which the cost comparison accounts for
-                if (kc->zip2 && g.kernel_pref != 1 && kc->zip2_lds(gr.A) <= LDS_BUDGET && (gr.zip || S == gr.A)) {
+                if (kc->zip2 && g.kernel_pref != 1 && kc->blocked_lds(gr.A) <= LDS_BUDGET && (gr.zip || S == gr.A)) {
                     size_t total = 0;
                     for (size_t L : lens) total += L;
                     const double rows = (double)g.cus * Z2WAVES * 4;
                     const double rb = kc->NP / 4.0;
-                    const double step_cycles = 5.8 * rb * rb * kc->NP;          // per wavefront-step (4 rows), measured ~2900 at N=20
+                    // per wavefront-step (4 segments): DPP/VALU form measured ~2900 at N=20; the MFMA form issues
+                    // (NP/4)^3 v_mfma_f64_4x4x4 at ~25.5 cycles each with two wavefronts per SIMD and nothing else
+                    const double step_cycles = kc->use3() ? 25.5 * rb * rb * rb * 0.55 : 5.8 * rb * rb * kc->NP;
                     size_t seg_blk = 16;
                     double slots = 0.0, cost_blk = 1e300;
                     // a workgroup takes 32 consecutive segments of ONE chunk: rows are allocated per chunk in 32s
@@ -716,10 +817,11 @@ struct PlanBuilder {
                 const double span = toks > 0.0 ? cols / toks : 1.0;
                 const size_t head = handoff_head(gr);
                 const double nseg = std::max(1.0, toks / (double)gr.seglen);
-                if (g.seg_override) {
+                if (g.seg_override) {                 // tests: one checkpoint at a quarter of the forced segment length
                     if (gr.seglen >= 4 * R1_MIN_HEAD) {
                         gr.rank1 = true;
-                        gr.head_len = gr.head_min = gr.head_max = (int)round_up(gr.seglen / 4, 16);
+                        gr.head_len = (int)round_up(gr.seglen / 4, 16);
+                        gr.checkpoints.assign(1, gr.head_len);
                     }
                 } else {
                     const int best_m = estimate_handoff((double)gr.seglen, nseg, B, (double)head, kc->NP, kc->big_nslab, gr.A, g.cus).m;
@@ -727,8 +829,14 @@ struct PlanBuilder {
                         gr.rank1 = true;
                         gr.head_len = (int)head;
                         gr.seglen = std::max<size_t>(16, round_up(gr.seglen / best_m, 16));
-                        gr.head_min = (int)round_up(std::max<size_t>(64, (size_t)(R1_HEAD_MIN_COLUMNS / span)), 16);
-                        gr.head_max = (int)round_up(gr.seglen / 2, 16);
+                        // checkpoints: from ~8k alignment columns, each ~1.25x the previous (multiples of 16 tokens),
+                        // while at least an eighth of the segment would still be left for the mat-vec chain
+                        size_t c = round_up(std::max<size_t>(64, (size_t)(R1_HEAD_MIN_COLUMNS / span)), 16);
+                        while ((int)gr.checkpoints.size() < R1_MAX_ROUNDS && c + gr.seglen / 8 < gr.seglen) {
+                            gr.checkpoints.push_back((int)c);
+                            c = round_up(c + std::max<size_t>(16, c / 4), 16);
+                        }
+                        if (gr.checkpoints.empty()) gr.rank1 = false;
                     }
                 }
             }
@@ -852,13 +960,13 @@ struct PlanBuilder {
 
         Plan *q = p.get();
         auto up = [&](void **d, const void *h, size_t bytes) -> hipError_t {
-            hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 16));
+            hipError_t e = dev_alloc(d, std::max<size_t>(bytes, 16));
             if (e != hipSuccess) return e;
             if (bytes) e = hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
             return e;
         };
         auto zalloc = [&](void **d, size_t bytes) -> hipError_t {
-            hipError_t e = hipMalloc(d, std::max<size_t>(bytes, 16));
+            hipError_t e = dev_alloc(d, std::max<size_t>(bytes, 16));
             if (e == hipSuccess) e = hipMemset(*d, 0, std::max<size_t>(bytes, 16));   // padded operator columns stay 0
             return e;
         };
@@ -905,8 +1013,8 @@ struct PlanBuilder {
                 for (const BigBlock &bb : firsts) gr.big_blocks.push_back(bb);
             }
             e = up((void **)&gr.d_big_blocks, gr.big_blocks.data(), gr.big_blocks.size() * sizeof(BigBlock));
-            if (e == hipSuccess) e = hipMalloc((void **)&gr.d_Ctab, (size_t)B * gr.A * np2 * 8);
-            if (e == hipSuccess) e = hipMalloc((void **)&gr.d_cex, (size_t)B * gr.A * 4 + 16);
+            if (e == hipSuccess) e = dev_alloc((void **)&gr.d_Ctab, (size_t)B * gr.A * np2 * 8);
+            if (e == hipSuccess) e = dev_alloc((void **)&gr.d_cex, (size_t)B * gr.A * 4 + 16);
             if (gr.rank1) {
                 for (size_t i2 = 0; i2 < gr.seg_ids.size(); ++i2)
                 {
@@ -916,13 +1024,17 @@ struct PlanBuilder {
                 const size_t nrec = (size_t)B * segs.size();
                 if (e == hipSuccess) e = up((void **)&gr.d_tail_blocks, gr.tail_blocks.data(), gr.tail_blocks.size() * sizeof(BigBlock));
                 if (e == hipSuccess) e = zalloc((void **)&gr.d_r1flag, nrec * 4);
-                if (e == hipSuccess) e = hipMalloc((void **)&gr.d_r1u, std::max<size_t>(nrec * kc->NP * 8, 16));
-                if (e == hipSuccess) e = hipMalloc((void **)&gr.d_r1alpha, std::max<size_t>(nrec * kc->NP * 8, 16));
+                if (e == hipSuccess) e = zalloc((void **)&gr.d_r1at, nrec * 4);
+                if (e == hipSuccess) e = dev_alloc((void **)&gr.d_r1u, std::max<size_t>(nrec * kc->NP * 8, 16));
+                if (e == hipSuccess) e = dev_alloc((void **)&gr.d_r1alpha, std::max<size_t>(nrec * kc->NP * 8, 16));
             }
         }
-        if (e == hipSuccess) e = hipMalloc((void **)&q->d_params, (size_t)B * q->pstride * 8);
-        if (e == hipSuccess) e = hipMalloc((void **)&q->d_out, (size_t)B * std::max(n_chunks, 1) * 8);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_params, (size_t)B * q->pstride * 8, hipHostMallocDefault);
+        if (e == hipSuccess) e = dev_alloc((void **)&q->d_params, (size_t)B * q->pstride * 8);
+        if (e == hipSuccess) e = dev_alloc((void **)&q->d_out, (size_t)B * std::max(n_chunks, 1) * 8);
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+            e = hipHostMalloc((void **)&q->h_params[k], (size_t)B * q->pstride * 8, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&q->ev_params[k], hipEventDisableTiming);
+        }
         if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_out, (size_t)B * std::max(n_chunks, 1) * 8, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&q->h_out_dev, q->h_out, 0);
         if (e != hipSuccess) {
@@ -942,7 +1054,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     key.reserve(n_chunks + 5);
     for (int f = 0; f < n_chunks; ++f) key.push_back(chunks[f]->id);
     key.push_back((uint64_t)N); key.push_back((uint64_t)S); key.push_back((uint64_t)B);
-    key.push_back((uint64_t)g.seg_override); key.push_back((uint64_t)(g.compression * 4 + g.kernel_pref + (op_mode ? 64 : 0)));
+    key.push_back((uint64_t)g.seg_override); key.push_back((uint64_t)(g.compression * 4 + g.kernel_pref + (op_mode ? 64 : 0) + g.blocked_variant * 128));
     for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
         if ((*it)->key == key) {
             g_plans.splice(g_plans.begin(), g_plans, it);
@@ -1017,12 +1129,14 @@ int check_args(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, 
 
 // Enqueue everything for one batch on `stream`.  Results land in plan->d_out ([B][n_chunks]).
 // Pad the caller's parameters into the plan's pinned staging buffer (host work only).
-void stage_params(Plan *p, const double *pis, const double *Ts, const double *Es)
+int stage_params(Plan *p, const double *pis, const double *Ts, const double *Es, bool fixed_slot = false)
 {
     KernelChoice *kc = p->kc;
     const int N = p->N, S = p->S, NP = kc->NP, B = p->B;
+    p->slot = fixed_slot ? 0 : p->slot ^ 1;          // (a captured graph always copies from slot 0)
+    if (p->ev_used[p->slot]) HIP_TRY(hipEventSynchronize(p->ev_params[p->slot]));
     for (int b = 0; b < B; ++b) {
-        double *pp = p->h_params + (size_t)b * p->pstride;
+        double *pp = p->h_params[p->slot] + (size_t)b * p->pstride;
         std::memset(pp, 0, p->pstride * 8);
         const double *pi = pis + (size_t)b * N, *T = Ts + (size_t)b * N * N, *E = Es + (size_t)b * N * S;
         for (int i = 0; i < N; ++i) pp[i] = pi[i];
@@ -1032,6 +1146,7 @@ void stage_params(Plan *p, const double *pis, const double *Ts, const double *Es
         for (int s = 0; s < S; ++s)
             for (int i = 0; i < N; ++i) Et[(size_t)s * NP + i] = E[(size_t)i * S + s];
     }
+    return IMC_OK;
 }
 
 // Enqueue one batch evaluation on `stream`: parameter upload, propagate, stitch.  Per-chunk results are written
@@ -1041,7 +1156,13 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
 {
     KernelChoice *kc = p->kc;
     const int N = p->N, S = p->S, NP = kc->NP, B = p->B;
-    HIP_TRY(hipMemcpyAsync(p->d_params, p->h_params, (size_t)B * p->pstride * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(p->d_params, p->h_params[p->slot], (size_t)B * p->pstride * 8, hipMemcpyHostToDevice, stream));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    if (cap == hipStreamCaptureStatusNone) {         // the slot may be rewritten once this upload has been consumed
+        HIP_TRY(hipEventRecord(p->ev_params[p->slot], stream));
+        p->ev_used[p->slot] = true;
+    }
 
     uint64_t *lp = p->lp;
     lp[0] = p->n_segs; lp[1] = p->n_vecs; lp[2] = lp[3] = lp[4] = lp[5] = lp[6] = lp[7] = 0;
@@ -1069,8 +1190,10 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
             ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
-            ba.phase = gr.rank1 ? 1 : 0; ba.head_len = gr.head_len; ba.r1flag = gr.d_r1flag; ba.r1u = gr.d_r1u;
+            ba.phase = gr.rank1 ? 1 : 0; ba.t_from = 0; ba.t_to = gr.rank1 ? gr.checkpoints[0] : INT_MAX;
+            ba.r1flag = gr.d_r1flag; ba.r1at = gr.d_r1at; ba.r1u = gr.d_r1u;
             ba.r1alpha = gr.d_r1alpha; ba.n_segs = p->n_segs;
+            if (gr.rank1) HIP_TRY(hipMemsetAsync(gr.d_r1flag, 0, (size_t)B * p->n_segs * 4, stream));   // nothing certified yet
             hipLaunchKernelGGL(kc->big_table_raw, dim3((unsigned)S, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
             if (gr.zip) {   // merged tokens, one launch per dictionary depth (tokens of a depth are independent)
@@ -1115,21 +1238,28 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                                stream, ba, (const BigBlock *)gr.d_big_blocks);
             note(std::string(kc->big_prop_waves != kc->G ? "k_big_propagate_s<" : "k_big_propagate<") + std::to_string(kc->G) + ">" + strm);
             if (gr.rank1 && !gr.tail_blocks.empty()) {
-                // heads are done: certify which operators collapsed to rank one, finish those on the mat-vec chain and
-                // the others on the GEMM chain (both launches cover all tails; a workgroup whose segment belongs to
-                // the other kernel exits at once, so no host round trip is needed)
-                HIP_TRY(hipGetLastError());
-                hipLaunchKernelGGL(k_rank1_check, dim3((unsigned)gr.tail_blocks.size(), (unsigned)B), dim3(256), 0, stream, ba,
-                                   (const BigBlock *)gr.d_tail_blocks, NP);
-                HIP_TRY(hipGetLastError());
-                const unsigned grid = B >= 8 ? 8u * (unsigned)gr.tail_blocks.size() * (unsigned)((B + 7) / 8)
-                                             : (unsigned)gr.tail_blocks.size() * (unsigned)B;
-                hipLaunchKernelGGL(kc->big_vec_tail, dim3(grid), dim3(kc->big_vec_waves * 64), 0, stream, ba,
-                                   (const BigBlock *)gr.d_tail_blocks, (int)gr.tail_blocks.size(), B);
-                HIP_TRY(hipGetLastError());
-                ba.phase = 2;
-                hipLaunchKernelGGL(kc->big_prop, dim3((unsigned)gr.big_blocks.size(), (unsigned)B), dim3(kc->big_prop_waves * 64), kc->big_lds,
-                                   stream, ba, (const BigBlock *)gr.d_big_blocks);
+                // The first round of heads is done.  Per checkpoint: certify which of the operators still on the GEMM
+                // chain collapsed to rank one, then run the others up to the next checkpoint; after the last one the
+                // certified segments finish on the mat-vec chain and the rest on the GEMM chain.  Every launch covers
+                // all segments and a workgroup with nothing to do exits at once, so there is no host round trip.
+                for (size_t r = 0; r < gr.checkpoints.size(); ++r) {
+                    HIP_TRY(hipGetLastError());
+                    ba.t_to = gr.checkpoints[r];
+                    hipLaunchKernelGGL(k_rank1_check, dim3((unsigned)gr.tail_blocks.size(), (unsigned)B), dim3(256), 0, stream, ba,
+                                       (const BigBlock *)gr.d_tail_blocks, NP);
+                    HIP_TRY(hipGetLastError());
+                    ba.t_from = gr.checkpoints[r];
+                    ba.t_to = r + 1 < gr.checkpoints.size() ? gr.checkpoints[r + 1] : INT_MAX;
+                    if (r + 1 == gr.checkpoints.size()) {   // the mat-vec tails first: they are the long launch
+                        const unsigned grid = B >= 8 ? 8u * (unsigned)gr.tail_blocks.size() * (unsigned)((B + 7) / 8)
+                                                     : (unsigned)gr.tail_blocks.size() * (unsigned)B;
+                        hipLaunchKernelGGL(kc->big_vec_tail, dim3(grid), dim3(kc->big_vec_waves * 64), 0, stream, ba,
+                                           (const BigBlock *)gr.d_tail_blocks, (int)gr.tail_blocks.size(), B);
+                        HIP_TRY(hipGetLastError());
+                    }
+                    hipLaunchKernelGGL(kc->big_prop, dim3((unsigned)gr.big_blocks.size(), (unsigned)B), dim3(kc->big_prop_waves * 64), kc->big_lds,
+                                       stream, ba, (const BigBlock *)gr.d_big_blocks);
+                }
                 note("rank1-handoff");
             }
             if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A); }
@@ -1142,14 +1272,16 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
             ba.Ctab = nullptr; ba.cex = nullptr;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
-            if (!kc->zip2_attr_set) {
-                HIP_TRY(hipFuncSetAttribute((const void *)kc->zip2, hipFuncAttributeMaxDynamicSharedMemorySize,
+            const bool v3 = kc->use3();
+            bool &attr_set = v3 ? kc->zip3_attr_set : kc->zip2_attr_set;
+            if (!attr_set) {
+                HIP_TRY(hipFuncSetAttribute((const void *)(v3 ? kc->zip3 : kc->zip2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)LDS_BUDGET));
-                kc->zip2_attr_set = true;
+                attr_set = true;
             }
-            hipLaunchKernelGGL(kc->zip2, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64),
-                               kc->zip2_lds(gr.A), stream, ba);
-            note("k_zpropagate2<" + std::to_string(NP / 4) + ">" + strm);
+            hipLaunchKernelGGL(v3 ? kc->zip3 : kc->zip2, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64),
+                               kc->blocked_lds(gr.A), stream, ba);
+            note(std::string(v3 ? "k_zpropagate3<" : "k_zpropagate2<") + std::to_string(NP / 4) + ">" + strm);
             if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A); }
             else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }
         } else if (gr.zip) {
@@ -1206,37 +1338,21 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
     return IMC_OK;
 }
 
-// After a call has been synchronised: how many operator segments the rank-one test saw and how many it certified,
-// and the head length of the NEXT call of this plan: while every test passes the head shrinks by a quarter (the
-// HMM's memory is shorter than assumed); the first failure returns to the last length that passed everywhere and
-// stops the shrinking, later failures (the parameters moved) lengthen it by half.  Optimisers and MCMC
-// chains call with slowly moving parameters, so a few calls settle it; a failed test only costs that call its
-// speed-up (the segment finishes on the GEMM chain), never its result.
+// After a call has been synchronised: how many operator segments the rank-one test saw and how many it certified
+// (at any checkpoint).  Statistics only: nothing here feeds back into later calls.
 void collect_rank1_stats(Plan *p)
 {
     g.r1_checked = g.r1_collapsed = 0;
     for (Group &gr : p->groups) {
-        if (!gr.rank1 || gr.r1_segs.empty()) continue;
+        if (!gr.rank1 || gr.r1_segs.empty() || gr.checkpoints.empty()) continue;
         std::vector<int> flags((size_t)p->B * p->n_segs);
         if (hipMemcpy(flags.data(), gr.d_r1flag, flags.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) continue;
-        uint64_t checked = 0, collapsed = 0;
         for (int b = 0; b < p->B; ++b)
             for (const auto &sl : gr.r1_segs) {
-                if ((int)sl.second <= gr.head_len) continue;
-                ++checked;
-                collapsed += flags[(size_t)b * p->n_segs + sl.first] ? 1 : 0;
+                if ((int)sl.second <= gr.checkpoints[0]) continue;
+                ++g.r1_checked;
+                g.r1_collapsed += flags[(size_t)b * p->n_segs + sl.first] ? 1 : 0;
             }
-        g.r1_checked += checked;
-        g.r1_collapsed += collapsed;
-        if (!checked || g.seg_override || p->graph) continue;   // (a captured graph has the head length baked in)
-        if (collapsed == checked) {
-            gr.head_good = gr.head_len;
-            if (!gr.head_frozen) gr.head_len = std::max(gr.head_min, (int)round_up((size_t)gr.head_len * 3 / 4, 16));
-        } else {   // back to the last length that passed everywhere (or half as long again if there is none above)
-            const int grown = (int)round_up((size_t)gr.head_len * 3 / 2, 16);
-            gr.head_len = std::min(gr.head_max, (gr.head_good > gr.head_len && !gr.head_frozen) ? gr.head_good : grown);
-            gr.head_frozen = true;
-        }
     }
 }
 
@@ -1249,7 +1365,7 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
     HIP_TRY(hipSetDevice(g.device));
     Plan *p = nullptr;
     if (int rc = build_plan(chunks, n_chunks, N, S, B, false, &p)) return rc;
-    stage_params(p, pis, Ts, Es);
+    if (int rc = stage_params(p, pis, Ts, Es, g.use_graphs)) return rc;
     // First call of a plan runs eagerly (kernel attributes get set); the second is captured into a hipGraph that
     // every later call replays: one graph launch instead of ~8 stream operations per evaluation.
     const bool use_graph = !g.profile && g.use_graphs && p->calls >= 1;
@@ -1297,7 +1413,7 @@ int run_state(const imc_obs *const *chunks, int n_chunks, bool op_mode, int B, i
     HIP_TRY(hipSetDevice(g.device));
     Plan *p = nullptr;
     if (int rc = build_plan(chunks, n_chunks, N, S, B, op_mode, &p)) return rc;
-    stage_params(p, pis, Ts, Es);
+    if (int rc = stage_params(p, pis, Ts, Es, g.use_graphs)) return rc;
     if (int rc = enqueue(p, g.stream, p->h_out_dev)) return rc;
     ++p->calls;
     for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
@@ -1306,8 +1422,8 @@ int run_state(const imc_obs *const *chunks, int n_chunks, bool op_mode, int B, i
     const size_t n_state = (size_t)B * n_chunks * per, n_exp = (size_t)B * n_chunks * pere;
     double *d_state = nullptr;
     int *d_exp = nullptr;
-    hipError_t e = hipMalloc((void **)&d_state, std::max<size_t>(n_state * 8, 16));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_exp, std::max<size_t>(n_exp * 4, 16));
+    hipError_t e = dev_alloc((void **)&d_state, std::max<size_t>(n_state * 8, 16));
+    if (e == hipSuccess) e = dev_alloc((void **)&d_exp, std::max<size_t>(n_exp * 4, 16));
     if (e == hipSuccess) {
         const Level &last = p->levels.back();
         hipLaunchKernelGGL(k_export, dim3((unsigned)n_chunks, (unsigned)B), dim3(256), 0, g.stream, p->d_final_vec, n_chunks, N,
@@ -1317,8 +1433,8 @@ int run_state(const imc_obs *const *chunks, int n_chunks, bool op_mode, int B, i
     if (e == hipSuccess) e = hipMemcpyAsync(out_state, d_state, n_state * 8, hipMemcpyDeviceToHost, g.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_exp, d_exp, n_exp * 4, hipMemcpyDeviceToHost, g.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(g.stream);
-    (void)hipFree(d_state);
-    (void)hipFree(d_exp);
+    dev_free(d_state);
+    dev_free(d_exp);
     if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP, std::string("state export: ") + hipGetErrorString(e));
     return IMC_OK;
 }
@@ -1358,7 +1474,6 @@ int imc_set_device(int device)
 
 int imc_obs_create(const uint8_t *sym, size_t L, int nsym, imc_obs **out)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
     if (!out) return fail(IMC_ERR_ARG, "out is null");
     if (nsym < 1 || nsym > 256) return fail(IMC_ERR_ARG, "nsym must be in [1,256]");
     if (L && !sym) return fail(IMC_ERR_ARG, "sym is null");
@@ -1380,7 +1495,6 @@ int imc_obs_create_i32(const int32_t *sym, size_t L, int nsym, imc_obs **out)
             return fail(IMC_ERR_SYMBOL, "symbol " + std::to_string(sym[t]) + " at column " + std::to_string(t) + " outside [0,nsym)");
         tmp[t] = (uint8_t)sym[t];
     }
-    std::lock_guard<std::mutex> lk(g_mu);
     return obs_upload(tmp.data(), L, nsym, out);
 }
 
@@ -1392,7 +1506,6 @@ int imc_obs_create_from_text(const char *path, int nsym, imc_obs **out)
     const imc::IoResult r = imc::read_observation_file(path, nsym, sym);
     if (r.code) return fail(r.code, r.msg);
     if (sym.size() >= (size_t)1 << 31) return fail(IMC_ERR_ARG, "chunk too long (limit 2^31-1 columns per chunk)");
-    std::lock_guard<std::mutex> lk(g_mu);
     return obs_upload(sym.data(), sym.size(), nsym, out);
 }
 
@@ -1495,10 +1608,9 @@ int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, 
     hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g.stream;
     Plan *p = nullptr;
     if (int rc = build_plan(chunks, n_chunks, N, S, B, false, &p)) return rc;
-    // the pinned staging buffer is reused by the next call: wait for the previous upload first
-    HIP_TRY(hipStreamSynchronize(st));
-    if (p->calls > 0) collect_rank1_stats(p);   // the previous call of this plan has finished: adapt the hand-off head
-    stage_params(p, pis, Ts, Es);
+    // no stream synchronisation here: the parameters go through the two-slot pinned staging (stage_params waits only
+    // for the upload issued two calls ago), and nothing is read back - the call returns once everything is enqueued
+    if (int rc = stage_params(p, pis, Ts, Es, g.use_graphs)) return rc;
     if (int rc = enqueue(p, st, p->d_out)) return rc;
     ++p->calls;
     for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
@@ -1572,6 +1684,14 @@ int imc_set_rank1_handoff(int on)
     std::lock_guard<std::mutex> lk(g_mu);
     if (g.rank1_handoff != (on != 0)) drop_plans();   // cached plans were built for the other setting
     g.rank1_handoff = on != 0;
+    return IMC_OK;
+}
+
+int imc_set_blocked_kernel(int variant)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (variant != 2 && variant != 3) return fail(IMC_ERR_ARG, "blocked kernel variant must be 2 (VALU/DPP) or 3 (fp64 MFMA)");
+    g.blocked_variant = variant;            // (part of the plan key: cached plans of the other variant stay valid)
     return IMC_OK;
 }
 

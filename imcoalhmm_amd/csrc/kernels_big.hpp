@@ -41,11 +41,13 @@ struct BigArgs {
     int *cex;                     // [B][A] power-of-two exponents of the table entries
     double *P;                    // level-0 results (see kernels_stitch.hpp for the layout)
     int *EX;
-    // rank-one hand-off (see k_rank1_check): 0 = whole segments; 1 = heads only (operator segments stop after
-    // head_len tokens); 2 = tails of the segments that did NOT collapse, continued from their stored block
+    // rank-one hand-off (see k_rank1_check).  phase 0: whole segments.  phase 1: one ROUND of the GEMM chain over the
+    // operator segments (first segments run on the mat-vec chain kernel): tokens [t_from, t_to) of every segment that
+    // is longer than t_from and not yet certified; t_from > 0 continues from the block stored by the previous round.
     int phase;
-    int head_len;
-    int *r1flag;                  // [B][n_segs] 1: the head operator is rank one within R1_TOL
+    int t_from, t_to;
+    int *r1flag;                  // [B][n_segs] 1: the operator after r1at tokens is rank one within R1_TOL
+    int *r1at;                    // [B][n_segs] token count at which that was certified (the tail starts there)
     double *r1u, *r1alpha;        // [B][n_segs][NP] its column direction u and column scales alpha
     uint32_t n_segs;
 };
@@ -324,11 +326,11 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
     const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
     const int *cex = a.cex + (size_t)b * a.A;
 
-    // phases of the rank-one hand-off: which tokens this launch covers
-    const bool tail = a.phase == 2;
+    // rounds of the rank-one hand-off: which tokens this launch covers
+    const bool tail = a.phase == 1 && a.t_from > 0;   // continue from the stored block
     if (a.phase != 0 && first) return;             // hand-off mode: first segments run on the mat-vec chain kernel
-    if (tail && (len <= a.head_len || a.r1flag[(size_t)b * a.n_segs + bk.seg])) return;   // nothing left for the GEMM chain
-    const int t_end = (a.phase == 1 && !first && len > a.head_len) ? a.head_len : len;
+    if (tail && (len <= a.t_from || a.r1flag[(size_t)b * a.n_segs + bk.seg])) return;   // finished, or certified: the mat-vec chain takes over
+    const int t_end = (a.phase == 1 && len > a.t_to) ? a.t_to : len;
     const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
     double *Pout = a.P + gv * NP;
     // initial slab: identity columns, or (first segment, slab 0) column 0 = pi .* E[:,o_0], or (tail) the stored block
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(NT * 64) void k_big_propagate(BigArgs a, const BigB
     int which = 0;
     // the first A panel of the NEXT token is fetched while the current step finishes (exponent, write-back),
     // so no step starts with an exposed L2 round trip
-    const int t_begin = tail ? a.head_len : first ? 1 : 0;
+    const int t_begin = tail ? a.t_from : first ? 1 : 0;
     const size_t aoff0 = (size_t)ar0 * NP + 2 * ac0, aoff1 = (size_t)ar1 * NP + 2 * ac1;
     double2 sa0 = double2{0.0, 0.0}, sa1 = double2{0.0, 0.0};
     if (t_begin < t_end) {
@@ -466,7 +468,7 @@ struct BigVec {
 };
 
 // TAIL = true is the second half of the rank-one hand-off (k_rank1_check): the chain starts from the collapsed
-// operator's column direction u after head_len tokens and ends by writing the operator block u' alpha^T.
+// operator's column direction u after r1at tokens and ends by writing the operator block u' alpha^T.
 template <int NT, bool TAIL = false>
 __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a, const BigBlock *blocks, int n_blocks, int B)
 {
@@ -505,13 +507,13 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     // pi, an operator segment continues from u if (and only if) its head was certified rank one
     const bool from_u = TAIL && !(sd.first & SEG_FIRST);
     if (from_u) {
-        if (len <= a.head_len || !a.r1flag[(size_t)b * a.n_segs + bk.seg]) return;
+        if (!a.r1flag[(size_t)b * a.n_segs + bk.seg]) return;   // (workgroup-uniform)
         for (int k = tid; k < NP; k += THREADS) xs[0][k] = k < a.N ? a.r1u[r1 + k] : 0.0;
     } else {
         const int tok0 = seg_token(tokp, wide, 0);
         for (int k = tid; k < NP; k += THREADS) xs[0][k] = k < a.N ? pp[k] * Etg[(size_t)tok0 * a.PP + k] : 0.0;
     }
-    const int t0 = from_u ? a.head_len : 1;        // first token applied as an operator
+    const int t0 = from_u ? a.r1at[(size_t)b * a.n_segs + bk.seg] : 1;        // first token applied as an operator
     if (tid < 3) smax[tid] = 0ull;
     __syncthreads();
 
@@ -662,11 +664,11 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
     const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
     const int *cex = a.cex + (size_t)b * a.A;
 
-    // phases of the rank-one hand-off: which tokens this launch covers
-    const bool tail = a.phase == 2;
+    // rounds of the rank-one hand-off: which tokens this launch covers
+    const bool tail = a.phase == 1 && a.t_from > 0;   // continue from the stored block
     if (a.phase != 0 && first) return;             // hand-off mode: first segments run on the mat-vec chain kernel
-    if (tail && (len <= a.head_len || a.r1flag[(size_t)b * a.n_segs + bk.seg])) return;   // nothing left for the GEMM chain
-    const int t_end = (a.phase == 1 && !first && len > a.head_len) ? a.head_len : len;
+    if (tail && (len <= a.t_from || a.r1flag[(size_t)b * a.n_segs + bk.seg])) return;   // finished, or certified: the mat-vec chain takes over
+    const int t_end = (a.phase == 1 && len > a.t_to) ? a.t_to : len;
     const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
     double *Pout = a.P + gv * NP;
     // initial slab: identity columns, or (first segment, slab 0) column 0 = pi .* E[:,o_0], or (tail) the stored block
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
     }
     long long ex = tail ? (long long)a.EX[gv + (c0 < a.N ? c0 : 0)] : 0;
     int which = 0;
-    const int t_begin = tail ? a.head_len : first ? 1 : 0;
+    const int t_begin = tail ? a.t_from : first ? 1 : 0;
     double2 sa[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) sa[k] = double2{0.0, 0.0};
@@ -828,12 +830,15 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
 // Rank-one hand-off.  A product of many positive operators forgets its input: after enough columns every column of a
 // segment's transfer operator P points in the same direction (Birkhoff contraction), P = u alpha^T, and the rest of
 // the segment only has to propagate the VECTOR u - N^2 instead of N^3 work per step.  The hand-off is certified,
-// not assumed: after head_len tokens this kernel tests, component-wise,
+// not assumed: at a checkpoint (t_to tokens into the segment) this kernel tests, component-wise,
 //     | P[i][c] s_* / (P[i][c*] s_c) - 1 | <= R1_TOL      for every i, c   (s_c = column sums, c* = the largest column)
 // and only then records u = P[:, c*], alpha_c = s_c / s_*.  A component-wise relative bound survives every later
 // non-negative linear map unchanged, so the log-likelihood moves by at most R1_TOL (2^-42 = 2.3e-13) per collapsed
 // segment - absolute, in nats, on segments whose own log-likelihood is in the thousands.  Segments that fail the
 // test (slow mixing, structural zeros) simply continue on the GEMM chain.
+// The test is repeated at a fixed schedule of token counts (t_chk = a.t_to of the round that just ran): a segment
+// hands off at the first checkpoint it passes, so the head length is decided per segment and per evaluation from
+// the data alone - identical inputs give identical decisions (and bits), there is no state carried between calls.
 static constexpr double R1_TOL = 2.2737367544323206e-13;   // 2^-42
 
 __global__ __launch_bounds__(256) void k_rank1_check(BigArgs a, const BigBlock *blocks, int NP)
@@ -844,7 +849,8 @@ __global__ __launch_bounds__(256) void k_rank1_check(BigArgs a, const BigBlock *
     const int tid = threadIdx.x, b = blockIdx.y;
     const BigBlock bk = blocks[blockIdx.x];
     const SegDesc sd = a.segs[bk.seg];
-    if (bk.slab != 0 || (sd.first & SEG_FIRST) || (int)sd.len <= a.head_len) return;
+    if (bk.slab != 0 || (sd.first & SEG_FIRST) || (int)sd.len <= a.t_to) return;
+    if (a.r1flag[(size_t)b * a.n_segs + bk.seg]) return;      // certified at an earlier checkpoint (workgroup-uniform)
     const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
     const double *P = a.P + gv * NP;
     const int N = a.N;
@@ -880,10 +886,15 @@ __global__ __launch_bounds__(256) void k_rank1_check(BigArgs a, const BigBlock *
     __syncthreads();
     const bool ok = s_bad == 0u;
     const size_t r1 = ((size_t)b * a.n_segs + bk.seg) * NP;
-    if (tid == 0) a.r1flag[(size_t)b * a.n_segs + bk.seg] = ok ? 1 : 0;
-    if (ok)
+    if (!ok) return;                                           // the flag stays 0 (cleared at the start of the evaluation)
+    if (tid == 0) {
+        a.r1flag[(size_t)b * a.n_segs + bk.seg] = 1;
+        a.r1at[(size_t)b * a.n_segs + bk.seg] = a.t_to;
+    }
+    {
         for (int k = tid; k < NP; k += blockDim.x) {
             a.r1u[r1 + k] = k < N ? P[(size_t)k * NP + cs] : 0.0;
             a.r1alpha[r1 + k] = k < N ? s_sum[k] / ss : 0.0;
         }
+    }
 }

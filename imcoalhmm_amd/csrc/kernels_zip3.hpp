@@ -1,0 +1,308 @@
+// kernels_zip3.hpp - register-blocked token kernel on the fp64 matrix instruction: P <- C_tok * P with the segment's whole
+// transfer operator P (N x N, N <= 24) in registers and the step issued as v_mfma_f64_4x4x4_4b_f64.  Included by imcoal_fwd.hip.
+//
+// Why the matrix instruction here.  Measured on the MI355X (scratch microbenchmark): the DP FMA
+// units are shared by v_fma_f64 and v_mfma_f64 (a wavefront of each on one SIMD do not overlap), but the same FMAs cost
+// a quarter of the issue slots as MFMAs and draw less power: a bare v_fma_f64 loop sustains 50 TFLOP/s (4.7 cycles per
+// wavefront instruction at two wavefronts per SIMD, clock held at ~1.8 GHz), v_mfma_f64_4x4x4_4b 68 TFLOP/s (256 FMAs
+// per 12.75 cycles), and the MFMA form needs no cross-lane operand moves at all - k_zpropagate2 spends a fifth of its
+// VALU issue slots on DPP moves and ran at 36 TFLOP/s.
+//
+// v_mfma_f64_4x4x4_4b_f64 multiplies FOUR independent 4x4x4 blocks.  Lane l = 16 q + 4 blk + r supplies
+//     A[row r][k q] and B[k q][col r] of block blk and receives D[row q][col r]            (layout probed on the device)
+// so a result tile is already in the layout of a B operand: the new P feeds the next step with no data movement.
+//   * block blk of a wavefront = one segment (4 segments per wavefront, Z2SLOTS per workgroup, as in k_zpropagate2);
+//   * P is NT x NT tiles of 4 x 4 (NP = 4 NT): lane (q, blk, r) holds element (4K + q, 4J + r) of every tile (K, J);
+//   * per step, for every tile-row I the lane reads its NT A operands C_tok[4I + r][4K + q] from the LDS table (stored
+//     so that these are NT consecutive doubles) and issues NT*NT MFMAs: NT^3 per step, no other vector work;
+//   * a step that must leave a segment untouched (ragged ends, idle slots) uses the IDENTITY entry of the table, so
+//     the loop has no predication; the workgroup's segments are folded at the end exactly as in k_zpropagate2.
+#pragma once
+#include "kernels_zip2.hpp"
+
+template <int NT>
+struct Zip3Geom {
+    static constexpr int NP = 4 * NT;
+    static constexpr int NTE = NT & ~1;                 // K values a lane reads as 16-byte pairs
+    static constexpr int MAIN = NT * 16 * NTE;          // doubles: [I][q][r][K < NTE]
+    static constexpr int EXTRA = (NT & 1) ? NT * 16 : 0;   // doubles: [I][q][r] for K = NT - 1 (odd NT)
+    static constexpr int TOK = MAIN + EXTRA;            // = NP * NP doubles per operator
+    // where element (row, col) of an operator lives inside its TOK doubles
+    static __host__ __device__ constexpr int idx(int row, int col)
+    {
+        return (col >> 2) < NTE ? ((((row >> 2) * 4 + (col & 3)) * 4 + (row & 3)) * NTE + (col >> 2))
+                                : (MAIN + ((row >> 2) * 4 + (col & 3)) * 4 + (row & 3));
+    }
+    // table entries: A tokens + the identity; the same space later holds the Z2SLOTS exchange operators + the identity
+    static constexpr int entries(int A) { return (A > Z2SLOTS ? A : Z2SLOTS) + 1; }
+    static constexpr size_t op_doubles(int A) { return (size_t)entries(A) * TOK; }
+    static constexpr int ints(int A) { return (entries(A) + 1) & ~1; }
+    static constexpr size_t lds_bytes(int A) { return op_doubles(A) * 8 + (size_t)ints(A) * 4 + 16; }
+};
+
+// The NT A operands of tile-row I of operator Cz for this lane: C[4I + r][4K + q], K = 0..NT-1 (lane offsets
+// lo = (q*4 + r) * NTE into the main part of a tile-row and lx = q*4 + r into the odd part).
+template <int NT>
+__device__ __forceinline__ void zip3_load_row(double (&a)[NT], const double *Cz, int I, int lo, int lx)
+{
+    using Geo = Zip3Geom<NT>;
+    const double2 *m = reinterpret_cast<const double2 *>(Cz + I * 16 * Geo::NTE + lo);
+#pragma unroll
+    for (int k2 = 0; k2 < Geo::NTE / 2; ++k2) {
+        const double2 v = m[k2];
+        a[2 * k2] = v.x;
+        a[2 * k2 + 1] = v.y;
+    }
+    if constexpr (NT & 1) a[NT - 1] = Cz[Geo::MAIN + I * 16 + lx];
+}
+
+// Pout <- C * Pin for the four segments of the wavefront; Cz = this lane's segment's operator (table entry).  `a` holds
+// tile-row 0 of Cz on entry and tile-row 0 of Cn (the operator of the NEXT step) on exit: the LDS reads of a tile-row
+// are issued one tile-row (NT*NT MFMAs) ahead of their use, so no MFMA waits for LDS.
+template <int NT>
+__device__ __forceinline__ void zip3_step(const double (&Pin)[NT][NT], double (&Pout)[NT][NT], const double *Cz, const double *Cn,
+                                          double (&a)[NT], int lo, int lx)
+{
+#pragma unroll
+    for (int I = 0; I < NT; ++I) {
+        double an[NT];
+        if (I + 1 < NT) zip3_load_row<NT>(an, Cz, I + 1, lo, lx);
+        else zip3_load_row<NT>(an, Cn, 0, lo, lx);
+        __builtin_amdgcn_sched_barrier(0);         // keep the prefetch ahead of this tile-row's MFMAs
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+                Pout[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[K], Pin[K][J], K == 0 ? 0.0 : Pout[I][J], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int K = 0; K < NT; ++K) a[K] = an[K];
+    }
+}
+
+// common power-of-two rescale of a segment's operator: exponent of its largest entry over the segment's 16 lanes
+// (lanes 16 q + 4 blk + r: the xor partners 1, 2, 16, 32 stay inside the block)
+template <int NT>
+__device__ __forceinline__ void zip3_rescale(double (&P)[NT][NT], int &ex)
+{
+    double mx = 0.0;
+#pragma unroll
+    for (int K = 0; K < NT; ++K)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) mx = (P[K][J] > mx || P[K][J] != P[K][J]) ? P[K][J] : mx;
+#pragma unroll
+    for (int m = 1; m <= 32; m = (m == 2 ? 16 : m * 2)) {
+        const double o = __shfl_xor(mx, m, 64);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    int e = 0;
+    (void)frexp(mx, &e);
+    e = (mx > 0.0 && mx < INFINITY) ? e : 0;
+#pragma unroll
+    for (int K = 0; K < NT; ++K)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) P[K][J] = ldexp(P[K][J], -e);
+    ex += e;
+}
+
+template <int NT>
+__global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigArgs a)
+{
+    using Geo = Zip3Geom<NT>;
+    constexpr int NP = Geo::NP, TOK = Geo::TOK, THREADS = Z2WAVES * 64;
+    constexpr int EPT = (NP * NP + THREADS - 1) / THREADS;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *C = lds;                                                   // [entries][TOK]
+    int *cex = reinterpret_cast<int *>(C + Geo::op_doubles(a.A));    // [entries]
+    unsigned long long *smax = reinterpret_cast<unsigned long long *>(cex + Geo::ints(a.A));   // [2]
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const double *pp = a.params + (size_t)b * a.pstride;
+    const double *pi_p = pp;
+    const double *Tp = pp + a.PP;
+    const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
+    const int IDENT = a.A;                                             // table entry of the identity operator
+
+    // ---- operator table: raw symbols, the identity, then merged tokens in dictionary order ----
+    for (int idx = tid; idx < (a.S + 1) * NP * NP; idx += THREADS) {
+        const int sidx = idx / (NP * NP);
+        const int rem = idx - sidx * NP * NP;
+        const int i = rem / NP, j = rem - i * NP;
+        if (sidx < a.S) C[(size_t)sidx * TOK + Geo::idx(i, j)] = Etg[(size_t)sidx * a.PP + i] * Tp[(size_t)j * a.PP + i];
+        else C[(size_t)IDENT * TOK + Geo::idx(i, j)] = i == j ? 1.0 : 0.0;
+    }
+    if (tid < a.S) cex[tid] = 0;
+    if (tid == 0) cex[IDENT] = 0;
+    if (tid < 2) smax[tid] = 0ull;
+    __syncthreads();
+    for (int z = a.S; z < a.A; ++z) {
+        const int zl = a.tok_left[z], zr = a.tok_right[z];
+        const double *Cl = C + (size_t)zl * TOK, *Cr = C + (size_t)zr * TOK;
+        double *Cz = C + (size_t)z * TOK;
+        double vals[EPT];
+        double mx = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = tid + e * THREADS;
+            double acc = 0.0;
+            if (idx < NP * NP) {
+                const int i = idx / NP, j = idx - i * NP;
+#pragma unroll 4
+                for (int k = 0; k < NP; ++k) acc = fma(Cr[Geo::idx(i, k)], Cl[Geo::idx(k, j)], acc);
+            }
+            vals[e] = acc;
+            mx = (acc > mx || acc != acc) ? acc : mx;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const double o = __shfl_xor(mx, m, 64);
+            mx = (o > mx || o != o) ? o : mx;
+        }
+        if ((tid & 63) == 0) atomicMax(&smax[z & 1], (unsigned long long)__double_as_longlong(mx));
+        __syncthreads();
+        const double m = __longlong_as_double((long long)smax[z & 1]);
+        int e2 = 0;
+        (void)frexp(m, &e2);
+        e2 = (m > 0.0 && m < INFINITY) ? e2 : 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = tid + e * THREADS;
+            if (idx < NP * NP) {
+                const int i = idx / NP, j = idx - i * NP;
+                Cz[Geo::idx(i, j)] = ldexp(vals[e], -e2);
+            }
+        }
+        if (tid == 0) {
+            cex[z] = cex[zl] + cex[zr] + e2;
+            smax[(z + 1) & 1] = 0ull;
+        }
+        __syncthreads();
+    }
+
+    // ---- scan: one segment per MFMA block ----
+    const int lane = tid & 63;
+    const int q = lane >> 4, bq = (lane >> 2) & 3, r = lane & 3;
+    const int lo = (q * 4 + r) * Geo::NTE, lx = q * 4 + r;
+    const Z2Block blk = a.blocks[blockIdx.x];
+    const int slot = (tid >> 6) * 4 + bq;                   // 0..Z2SLOTS-1 within the workgroup
+    const bool valid = slot < (int)blk.n;
+    const uint32_t seg = blk.seg0 + (valid ? slot : 0);
+    const SegDesc sd = a.segs[seg];
+    const int len = valid ? (int)sd.len : 0;
+    const bool first = (sd.first & SEG_FIRST) != 0;
+    const uint8_t *tokp = sd.obs;
+
+    double P[NT][NT], Q[NT][NT];
+    {
+        const int tok0 = (valid && first) ? (int)tokp[0] : 0;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                const int i = 4 * K + q, c = 4 * J + r;
+                double v;
+                if (first) v = (c == 0 && i < a.N) ? pi_p[i] * Etg[(size_t)tok0 * a.PP + i] : 0.0;
+                else v = (i == c && i < a.N) ? 1.0 : 0.0;
+                P[K][J] = valid ? v : 0.0;
+            }
+    }
+    int ex = 0;
+    const int maxlen = wave_max_i32(len);
+    const int nfull = maxlen == 0 ? 0 : wave_min_i32(valid ? len / RESCALE_EVERY : INT_MAX);   // idle wavefronts still join the fold's barriers
+    // token t of this lane's segment, or the identity where the segment has none (token 0 of a first segment went into
+    // the initial P)
+    auto tok_at = [&](int t) { return (t < len && !(first && t == 0)) ? (int)tokp[t] : IDENT; };
+    // a step pair; `a` carries the prefetched first tile-row of t0's operator in and of tn's operator out
+    double arow[NT];
+    auto two_steps = [&](int t0, int t1, int tn) {
+        zip3_step<NT>(P, Q, C + (size_t)t0 * TOK, C + (size_t)t1 * TOK, arow, lo, lx);
+        zip3_step<NT>(Q, P, C + (size_t)t1 * TOK, C + (size_t)tn * TOK, arow, lo, lx);
+        ex += cex[t0] + cex[t1];
+    };
+    const int head_end = min(RESCALE_EVERY, maxlen);
+    if (head_end > 0) zip3_load_row<NT>(arow, C + (size_t)tok_at(0) * TOK, 0, lo, lx);
+    for (int t = 0; t < head_end; t += 2) two_steps(tok_at(t), tok_at(t + 1), tok_at(t + 2));
+    zip3_rescale<NT>(P, ex);
+    for (int bi = 1; bi < nfull; ++bi) {
+        const uint4 ob = *reinterpret_cast<const uint4 *>(tokp + (size_t)bi * RESCALE_EVERY);
+        uint32_t w0 = ob.x, w1 = ob.y, w2 = ob.z, w3 = ob.w;
+        zip3_load_row<NT>(arow, C + (size_t)(w0 & 0xffu) * TOK, 0, lo, lx);
+#pragma unroll 1
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const uint32_t w = w0;
+            w0 = w1; w1 = w2; w2 = w3; w3 = (uint32_t)IDENT;   // (after the block's last word the prefetch reads the identity)
+            two_steps(w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu);
+            two_steps((w >> 16) & 0xffu, w >> 24, w0 & 0xffu);
+        }
+        zip3_rescale<NT>(P, ex);
+    }
+    const int tail0 = max(RESCALE_EVERY, nfull * RESCALE_EVERY);
+    if (tail0 < maxlen) zip3_load_row<NT>(arow, C + (size_t)tok_at(tail0) * TOK, 0, lo, lx);
+    for (int t = tail0; t < maxlen; t += 2) {
+        two_steps(tok_at(t), tok_at(t + 1), tok_at(t + 2));
+        if (((t + 2) & (RESCALE_EVERY - 1)) == 0) zip3_rescale<NT>(P, ex);
+    }
+    zip3_rescale<NT>(P, ex);
+
+    // ---- fold the workgroup's segments into one: P_0 <- P_{n-1} ... P_1 P_0 (binary tree through LDS) ----
+    // The operator table is dead once every wavefront is here; its space becomes the exchange area (slot s holds the
+    // operator of segment s in the table's own layout, entry Z2SLOTS the identity), and a fold step is an ordinary
+    // token step whose "token operator" is the partner slot's P.
+    for (int stride = 1; stride < Z2SLOTS; stride <<= 1) {
+        if ((int)blk.n <= stride) break;          // workgroup-uniform
+        __syncthreads();                          // table (or previous level's exchange data) no longer read
+        if (stride == 1) {
+            for (int idx = tid; idx < NP * NP; idx += THREADS) {
+                const int i = idx / NP, j = idx - i * NP;
+                C[(size_t)Z2SLOTS * TOK + Geo::idx(i, j)] = i == j ? 1.0 : 0.0;
+            }
+            if (tid == 0) cex[Z2SLOTS] = 0;
+        }
+        if (valid && (slot & stride) && !(slot & (stride - 1))) {   // this slot is a partner ("hi") at this level
+            double *dst = C + (size_t)slot * TOK;
+#pragma unroll
+            for (int K = 0; K < NT; ++K)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) dst[Geo::idx(4 * K + q, 4 * J + r)] = P[K][J];
+            if (q == 0 && r == 0) cex[slot] = ex;
+        }
+        __syncthreads();
+        const bool act = valid && !(slot & (2 * stride - 1)) && slot + stride < (int)blk.n;
+        const int src = act ? slot + stride : Z2SLOTS;
+        zip3_load_row<NT>(arow, C + (size_t)src * TOK, 0, lo, lx);
+        zip3_step<NT>(P, Q, C + (size_t)src * TOK, C + (size_t)src * TOK, arow, lo, lx);
+        ex += cex[src];
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) P[K][J] = Q[K][J];
+        zip3_rescale<NT>(P, ex);
+    }
+
+    if (slot == 0) {
+        const size_t gv = (size_t)b * a.n_vecs_total + blk.out_vec0;
+        double *Pout = a.P + gv * NP;
+        if (blk.first) {
+            if (r == 0) {
+#pragma unroll
+                for (int K = 0; K < NT; ++K)
+                    if (4 * K + q < a.N) Pout[4 * K + q] = P[K][0];
+            }
+            if (q == 0 && r == 0) a.EX[gv] = ex;
+        } else {
+#pragma unroll
+            for (int K = 0; K < NT; ++K)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    const int i = 4 * K + q, c = 4 * J + r;
+                    if (i < a.N && c < a.N) Pout[(size_t)i * NP + c] = P[K][J];
+                }
+            if (q == 0) {
+#pragma unroll
+                for (int J = 0; J < NT; ++J)
+                    if (4 * J + r < a.N) a.EX[gv + 4 * J + r] = ex;
+            }
+        }
+    }
+}

@@ -24,12 +24,18 @@
  *
  * Threads / processes: no HIP call is made before the first compute/create call, and the device
  * context is re-created lazily per PID, so Forwarders may be built inside multiprocessing
- * children as mcmc.py:112-121 does.  Calls are serialised internally by one mutex.
+ * children as mcmc.py:112-121 does.  HIP calls are serialised internally by one mutex; the O(L) host work of
+ * imc_obs_create* (validation, dictionary training, encoding) runs outside it.
  *
  * Environment (diagnostics only, read when a plan is built / the context is created):
  *   IMC_DEBUG=1        print the planner's cost estimates to stderr
  *   IMC_FORCE_LEVEL=k  pin the pair-dictionary level index (experiments; ignored if the level does not fit)
  *   IMC_GRAPH=1        replay each plan as a hipGraph (measured: no gain)
+ *   IMC_GUARD=1        test facility: every device buffer is its own virtual-memory mapping that ends flush against an
+ *                      unmapped range, so any access past a buffer's end faults at once (tests/test_gpu_guard.py)
+ *
+ * fork(): a child forked AFTER the parent's first imc_* call gets IMC_ERR_HIP from every call (HIP state does not
+ * survive fork and nothing of the parent's is touched); fork chain processes first, or use the spawn start method.
  */
 #ifndef IMCOAL_FWD_H
 #define IMCOAL_FWD_H
@@ -103,8 +109,10 @@ int imc_forward_batch_per_chunk(const imc_obs *const *chunks, int n_chunks, int 
 
 /* Multi-GPU building block: partial sums stay on the device.  d_out_partial is a DEVICE pointer
  * to B doubles, written on `hip_stream` (a hipStream_t, may be NULL for the library's stream);
- * the call returns after enqueueing.  The caller then all-reduces d_out_partial over ranks
- * (RCCL sum).  Parameters are still host pointers. */
+ * the call returns after enqueueing (no stream synchronisation: the parameters are staged through two pinned
+ * slots, so only a third call in flight waits for the first one's upload).  The caller then all-reduces
+ * d_out_partial over ranks (RCCL sum).  Parameters are still host pointers.  Calls on one set of chunks must be
+ * issued in stream order (they share the plan's device buffers). */
 int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, int N, int S,
                              const double *pis, const double *Ts, const double *Es,
                              double *d_out_partial, void *hip_stream);
@@ -144,16 +152,20 @@ int imc_dictionary_reset(void);
  * accumulated device milliseconds and launch counts since the last reset, and resets. */
 int imc_profile_enable(int on);
 int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propagate, uint64_t *n_stitch);
-/* Rank-one hand-off of the GEMM-chain kernels (long segments, N > 24): a segment's transfer operator is tested after
- * a quarter of its tokens; if every column has collapsed onto one direction (component-wise, within 2^-44) the rest of
- * the segment propagates that vector instead of the N x N operator.  For the last imc_forward* call: how many operator
- * segments were tested and how many were certified.  IMC_RANK1=0 in the environment switches the hand-off off.
- * The head length adapts between calls of the same plan, so a repeated call may differ from the previous one in the
- * last bits (different association; observed: identical to 16 digits); switch the hand-off off for bit-for-bit
- * repeatability across calls. */
+/* Rank-one hand-off of the GEMM-chain kernels (long segments, N > 24): a segment's transfer operator is tested at a
+ * fixed schedule of checkpoints (token counts, from ~8k alignment columns, each ~1.25x the previous); at the first one
+ * where every column has collapsed onto one direction (component-wise, within 2^-42) the rest of the segment
+ * propagates that vector instead of the N x N operator.  The decision is taken per segment from the data of the
+ * evaluation alone - no state is carried between calls, so identical calls return identical bits.  For the last
+ * synchronous imc_forward* call: how many operator segments were tested and how many were certified.
+ * IMC_RANK1=0 in the environment switches the hand-off off. */
 int imc_last_rank1(uint64_t *checked, uint64_t *collapsed);
 /* Switch the hand-off on (default) or off for plans built from now on (A/B comparisons, tests). */
 int imc_set_rank1_handoff(int on);
+/* Register-blocked kernel for N <= 24: 3 (default) = k_zpropagate3, the step issued as v_mfma_f64_4x4x4 (the DP units
+ * are the same, the matrix form needs a quarter of the issue slots and no cross-lane moves); 2 = k_zpropagate2, the
+ * VALU / DPP form (A/B measurements, tests).  IMC_BLOCKED=2 in the environment selects 2 at start-up. */
+int imc_set_blocked_kernel(int variant);
 /* Description of the last launch plan, out8[0..7] = segments, vectors, per-column segment length,
  * executed vector-columns (per-column kernel), token segment length, executed vector-tokens (token
  * kernel), tokens in the compressed streams, token alphabet. */

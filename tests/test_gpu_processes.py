@@ -55,6 +55,47 @@ def test_forwarders_built_in_forked_children(tmp_path, oracle, hmm_params, examp
         assert abs(got - want) / abs(want) < 1e-11
 
 
+FORK_AFTER_INIT = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from imcoalhmm_amd import Forwarder, _capi
+    d = np.load(os.path.join(%r, "tests", "golden", "hmm_params.npz"))
+    pi, T, E = d["iso10_t0_pi"], d["iso10_t0_T"], d["iso10_t0_E"]
+    obs = (np.arange(5000) %% 3).astype(np.uint8)
+    f = Forwarder.from_array(obs, 3)
+    before = f.forward(pi, T, E)                     # the parent owns a live context, a cached plan, device buffers
+    pid = os.fork()
+    if pid == 0:                                     # child: every library call must be refused, nothing may touch HIP
+        code = 1
+        try:
+            Forwarder.from_array(obs, 3)
+        except _capi.ImcError as e:
+            code = 0 if "before fork" in str(e) else 2
+        try:
+            f.forward(pi, T, E)
+            code = 3
+        except _capi.ImcError as e:
+            code = code if "before fork" in str(e) else 4
+        os._exit(code)                               # (no interpreter teardown of inherited handles)
+    _, status = os.waitpid(pid, 0)
+    after = f.forward(pi, T, E)                      # the parent is unaffected
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+    assert before == after
+    print("ok")
+''') % (REPO, REPO)
+
+
+def test_fork_after_initialisation_is_refused(tmp_path):
+    """A child forked after the parent has used the GPU cannot use HIP (its state does not survive fork): every
+    library call in it must fail with a clear IMC_ERR_HIP instead of re-initialising or freeing the parent's device
+    pointers, and the parent must carry on unharmed.  (Reference pattern: mcmc.py:112-121 forks BEFORE building.)"""
+    script = tmp_path / "fork_after_init.py"
+    script.write_text(FORK_AFTER_INIT)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-2000:])
+
+
 def test_concurrent_calls_from_threads(oracle, hmm_params, example_pairs):
     """The Python shim releases the GIL inside the C call; the library serialises calls with one mutex.  Four
     threads hammering different Forwarders / models must each get their own correct value."""
