@@ -13,9 +13,26 @@ from . import _capi, hmm
 from .likelihood import build_hmms
 
 
-def shard_indices(n_chunks, rank, world_size):
-    """Static round-robin partition: chunk i -> rank i mod world_size."""
-    return list(range(rank, n_chunks, world_size))
+def shard_indices(n_chunks, rank, world_size, lengths=None):
+    """Static partition of chunk indices over ranks.
+
+    Without ``lengths``: round-robin, chunk i -> rank i mod world_size (right for equal-length chunks).
+    With ``lengths`` (columns per chunk): balanced by column count - chunks are dealt longest first, each to the rank
+    that so far holds the fewest columns (ties: the lowest rank), the classic LPT rule: no rank ends up with more than
+    4/3 of the optimum.  Deterministic, so every rank computes the same partition without communicating.  The
+    returned indices are in ascending order."""
+    if lengths is None:
+        return list(range(rank, n_chunks, world_size))
+    if len(lengths) != n_chunks:
+        raise ValueError("lengths must have one entry per chunk")
+    load = [0] * world_size
+    mine = []
+    for i in sorted(range(n_chunks), key=lambda k: (-int(lengths[k]), k)):
+        r = min(range(world_size), key=lambda q: (load[q], q))
+        load[r] += int(lengths[i])
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
 
 
 class DistributedLikelihood(object):
@@ -26,7 +43,8 @@ class DistributedLikelihood(object):
     and RCCL reduces it in place.
     """
 
-    def __init__(self, model, local_forwarders, group=None, device=None, local_eval=None, reduce_on_host=False):
+    def __init__(self, model, local_forwarders, group=None, device=None, local_eval=None, reduce_on_host=False,
+                 reduction="allreduce"):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -39,6 +57,13 @@ class DistributedLikelihood(object):
         self.device = device
         self._local_eval = local_eval or self._hip_eval
         self.reduce_on_host = reduce_on_host     # gloo rehearsals: reduce a host copy of the partial sums
+        # "allreduce": one all_reduce(sum) of B doubles (the order of the additions is the backend's);
+        # "ordered":   one all_gather of the per-rank partial sums, added on the host in rank order 0, 1, 2, ... from
+        #              0.0 - every rank gets the same bits whatever the collective's algorithm or topology (SURVEY.md
+        #              section 5: fixed reduction order for run-to-run reproducibility)
+        if reduction not in ("allreduce", "ordered"):
+            raise ValueError("reduction must be 'allreduce' or 'ordered'")
+        self.reduction = reduction
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
 
     def _hip_eval(self, pis, Ts, Es):
@@ -60,6 +85,13 @@ class DistributedLikelihood(object):
         partial = self._local_eval(pis, Ts, Es)
         if self.reduce_on_host:
             partial = partial.cpu()
+        if self.world_size > 1 and self.reduction == "ordered":
+            parts = [self._torch.empty_like(partial) for _ in range(self.world_size)]
+            self._dist.all_gather(parts, partial, group=self.group)
+            total = np.zeros(partial.shape[0], dtype=np.float64)
+            for part in parts:                          # rank order, left to right from 0.0
+                total = total + part.detach().cpu().numpy()
+            return total
         if self.world_size > 1:
             self._dist.all_reduce(partial, op=self._dist.ReduceOp.SUM, group=self.group)
         return partial.detach().cpu().numpy()

@@ -219,3 +219,85 @@ def test_proposal_sharding_world2():
         assert abs(single - want[0]) / abs(want[0]) < 1e-13
     assert sorted(r[3][0] for r in res) == [2, 3]          # 5 valid proposals split 3 + 2
     assert res[0][1] == res[1][1]
+
+
+def _worker_ordered(rank, world, port, q):
+    """Ragged chunk lengths, shards balanced by column count, per-rank partials combined in fixed rank order."""
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from imcoalhmm_amd.dist import DistributedLikelihood, shard_indices
+    lengths = [5000, 100, 2500, 2500, 40, 1200, 3000, 700, 60, 1800, 2200]
+    mine = shard_indices(len(lengths), rank, world, lengths=lengths)
+    # partial sums whose floating-point total depends on the order of the additions
+    vals = np.array([1e16, 1.0, -1e16, 3.0, 1e-3, 7.0, 2.0 ** -40, 5.0, -2.0, 1e8, 1.0 / 3.0])
+
+    def local_eval(pis, Ts, Es):
+        out = []
+        for b in range(pis.shape[0]):
+            t = 0.0
+            for i in mine:
+                t += float(vals[i]) * (b + 1)
+            out.append(t)
+        return torch.tensor(out, dtype=torch.float64)
+
+    class M(object):
+        def valid_parameters(self, p):
+            return True
+
+        def build_hidden_markov_model(self, p):
+            return np.ones(2) / 2, np.eye(2), np.ones((2, 3)) / 3
+
+    pis, Ts, Es = np.ones((3, 2)) / 2, np.stack([np.eye(2)] * 3), np.ones((3, 2, 3)) / 3
+    ordered = DistributedLikelihood(M(), [], local_eval=local_eval, reduction="ordered").forward_params_batch(pis, Ts, Es)
+    plain = DistributedLikelihood(M(), [], local_eval=local_eval).forward_params_batch(pis, Ts, Es)
+    q.put((rank, mine, ordered.tolist(), plain.tolist(), local_eval(pis, Ts, Es).tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ordered_reduction_and_balanced_shards(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ordered, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lengths = [5000, 100, 2500, 2500, 40, 1200, 3000, 700, 60, 1800, 2200]
+    shards = [r[1] for r in res]
+    assert sorted(sum(shards, [])) == list(range(len(lengths)))          # a partition
+    loads = [sum(lengths[i] for i in s) for s in shards]
+    assert max(loads) <= 4 * (sum(lengths) / world) / 3 + 1                # LPT bound; round-robin would not meet it
+    assert max(loads) - min(loads) <= max(lengths)
+    # every rank holds the same bits, and they are the rank-ordered host sum of the partials
+    for b in range(3):
+        want = 0.0
+        for r in res:
+            want += r[4][b]
+        assert all(r[2][b] == want for r in res), (b, [r[2][b] for r in res], want)
+    # (the plain all-reduce agrees to rounding, the ordered one exactly)
+    for r in res:
+        assert np.allclose(r[3], r[2], rtol=1e-12, atol=2.0)
+
+
+def test_shard_indices_properties():
+    sys.path.insert(0, REPO)
+    from imcoalhmm_amd.dist import shard_indices
+    rng = np.random.default_rng(4)
+    for world in (1, 2, 3, 8):
+        for n in (0, 1, 7, 64):
+            assert sorted(sum((shard_indices(n, r, world) for r in range(world)), [])) == list(range(n))
+            lengths = rng.integers(1, 10_000_000, size=n).tolist()
+            parts = [shard_indices(n, r, world, lengths=lengths) for r in range(world)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            if n >= world:
+                loads = [sum(lengths[i] for i in p) for p in parts]
+                assert max(loads) <= 4 * sum(lengths) / (3 * world) + max(lengths) / 3 + 1
+    with pytest.raises(ValueError):
+        shard_indices(3, 0, 2, lengths=[1, 2])

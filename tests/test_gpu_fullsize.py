@@ -96,3 +96,96 @@ def test_full_size_150_states_handoff_on_off_and_closed_form(big, hmm_params):
     got = f.forward(piq, Tq, Eq)
     assert _capi.last_rank1()[1] == _capi.last_rank1()[0] > 0       # a rank-one T collapses at once
     assert rel_err(got, want) < 1e-10, (got, want)
+
+
+# ---- BASELINE config[3] / config[4] at the size one of the 8 GPUs carries ---------------------------------------------
+
+def _rolled_chunks(pi, T, E, n_chunks, cols, seed, n_base=4):
+    """n_chunks distinct chunks of `cols` columns from n_base sampled alignments (rolled by different offsets): the
+    shape and statistics of independent chunks at a fraction of the generation time."""
+    base = [synth.sample_alignment(pi, T, E, cols, seed=seed + k) for k in range(n_base)]
+    return [np.roll(base[i % n_base], 7919 * (i // n_base + 1) * (i + 1)) for i in range(n_chunks)]
+
+
+def test_config3_slice_32_chunks_of_1e7(hmm_params, oracle):
+    """20 states, 32 x 1e7 columns (per-GPU slice of BASELINE config[3]): every chunk restarts from pi and the total is
+    the left-to-right sum (likelihood.py:33) - per-chunk values are bit-identical under a permutation of the chunks,
+    the total is the ordered sum of the per-chunk values, a rank-one T reproduces the count-only closed form for
+    every chunk, and one chunk's 2e6-column head matches the oracle."""
+    from imcoalhmm_amd.hmm import forward_chunks, forward_chunks_batch
+    pi, T, E = hmm_params("iso20_t0")
+    chunks = _rolled_chunks(pi, T, E, 32, 10_000_000, seed=20240100)
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    h = [f.handle for f in fw]
+    per = forward_chunks_batch(h, pi[None], T[None], E[None], per_chunk=True)[0]
+    assert "k_zpropagate3" in _capi.last_plan()["kernels"]
+    tot = forward_chunks(h, pi, T, E)
+    s = 0.0
+    for v in per:
+        s += v
+    assert tot == s and math.isfinite(tot)
+    perm = np.random.default_rng(3).permutation(32)
+    per_p = forward_chunks_batch([h[i] for i in perm], pi[None], T[None], E[None], per_chunk=True)[0]
+    assert all(per_p[k] == per[i] for k, i in enumerate(perm))          # chunks are independent: same bits anywhere
+    assert rel_err(forward_chunks([h[i] for i in perm], pi, T, E), tot) < 1e-13
+    # closed form, every chunk
+    n, nsym = 20, 3
+    rng = np.random.default_rng(21)
+    q = rng.random(n); q /= q.sum()
+    Tq = np.tile(q, (n, 1))
+    Eq = rng.random((n, nsym)); Eq /= Eq.sum(axis=1, keepdims=True)
+    piq = rng.random(n); piq /= piq.sum()
+    got = forward_chunks_batch(h, piq[None], Tq[None], Eq[None], per_chunk=True)[0]
+    for c, g in zip(chunks, got):
+        cnt = np.bincount(c[1:], minlength=nsym)
+        want = math.log(piq @ Eq[:, c[0]]) + float(cnt @ np.log(q @ Eq))
+        assert rel_err(g, want) < 1e-10, (g, want)
+    head = chunks[5][:2_000_000]
+    assert rel_err(Forwarder.from_array(head, 3).forward(pi, T, E), oracle.forward_scaled(pi, T, E, head)) < 1e-11
+
+
+def test_config4_slice_64_proposals_32_chunks_of_1e6(hmm_params, hmm_params_file, oracle):
+    """150 states, 64 proposals per step x 32 x 1e6 columns (per-GPU slice of BASELINE config[4]): row b of the batch
+    equals the single-theta call, 64 different rank-one T reproduce the closed form, and one chunk's head matches the
+    oracle for two of the proposals."""
+    from imcoalhmm_amd import models
+    from imcoalhmm_amd.hmm import forward_chunks, forward_chunks_batch
+    pi, T, E = hmm_params("im150_t0")
+    theta0 = hmm_params_file["im150_t0_theta"]
+    rng = np.random.default_rng(20240500)
+    thetas = theta0 * np.exp(0.1 * rng.standard_normal((64, len(theta0))))
+    thetas[0] = theta0
+    pis, Ts, Es = models.IsolationMigrationModel(75, 75).build_batch(thetas)
+    assert np.abs(Ts[0] - T).max() < 1e-12
+    chunks = _rolled_chunks(pi, T, E, 32, 1_000_000, seed=20240600)
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    h = [f.handle for f in fw]
+    per = forward_chunks_batch(h, pis, Ts, Es, per_chunk=True)
+    assert "k_big_vector" in _capi.last_plan()["kernels"]               # 2048 chains: the mat-vec chain, no operators
+    tot = forward_chunks_batch(h, pis, Ts, Es)
+    for b in (0, 17, 63):
+        s = 0.0
+        for v in per[b]:
+            s += v
+        assert tot[b] == s
+        one = forward_chunks(h, pis[b], Ts[b], Es[b])                   # another plan (B = 1), same value
+        assert rel_err(one, tot[b]) < 1e-12, (b, one, tot[b])
+    assert np.all(np.isfinite(tot)) and len(set(tot.tolist())) == 64
+    # closed form with 64 different rank-one models
+    n, nsym = 150, 3
+    rng = np.random.default_rng(22)
+    Q = rng.random((64, n)); Q /= Q.sum(axis=1, keepdims=True)
+    Tq = np.stack([np.tile(q, (n, 1)) for q in Q])
+    Eq = rng.random((64, n, nsym)); Eq /= Eq.sum(axis=2, keepdims=True)
+    Pq = rng.random((64, n)); Pq /= Pq.sum(axis=1, keepdims=True)
+    got = forward_chunks_batch(h, Pq, Tq, Eq, per_chunk=True)
+    cnts = [np.bincount(c[1:], minlength=nsym) for c in chunks]
+    for b in range(64):
+        lq = np.log(Q[b] @ Eq[b])
+        for k, c in enumerate(chunks):
+            want = math.log(Pq[b] @ Eq[b][:, c[0]]) + float(cnts[k] @ lq)
+            assert rel_err(got[b][k], want) < 1e-10, (b, k)
+    head = chunks[9][:150_000]
+    hf = Forwarder.from_array(head, 3)
+    for b in (0, 40):
+        assert rel_err(hf.forward(pis[b], Ts[b], Es[b]), oracle.forward_scaled(pis[b], Ts[b], Es[b], head)) < 1e-11
