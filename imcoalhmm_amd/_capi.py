@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libimcoal_fwd.so")
+# IMCOAL_FWD_LIB selects another build of the library (A/B measurements of compile-time variants); default: in-tree
+LIB_PATH = os.environ.get("IMCOAL_FWD_LIB") or os.path.join(_PKG, "libimcoal_fwd.so")
 
 IMC_OK = 0
 IMC_ERR_ARG = -1

@@ -26,7 +26,10 @@ struct Zip3Geom {
     static constexpr int NTE = NT & ~1;                 // K values a lane reads as 16-byte pairs
     static constexpr int MAIN = NT * 16 * NTE;          // doubles: [I][q][r][K < NTE]
     static constexpr int EXTRA = (NT & 1) ? NT * 16 : 0;   // doubles: [I][q][r] for K = NT - 1 (odd NT)
-    static constexpr int TOK = MAIN + EXTRA;            // = NP * NP doubles per operator
+#ifndef IMC_Z3PAD
+#define IMC_Z3PAD 0
+#endif
+    static constexpr int TOK = MAIN + EXTRA + IMC_Z3PAD;   // doubles per table entry: NP * NP (+ padding that staggers the banks of consecutive entries)
     // where element (row, col) of an operator lives inside its TOK doubles
     static __host__ __device__ constexpr int idx(int row, int col)
     {

@@ -1,7 +1,7 @@
 import csv, glob, os, sys, collections
 tag = sys.argv[1]
 base = 'gpurun_out/prof_%s' % tag
-for sub in ('fetch', 'write', 'sq', 'grbm'):
+for sub in ('fetch', 'write', 'sq', 'sq2', 'grbm'):
     files = sorted(glob.glob('%s/%s/*/*counter_collection.csv' % (base, sub)), key=os.path.getmtime, reverse=True)
     if not files: continue
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
