@@ -222,7 +222,8 @@ struct imc_obs {
     int device;
     int nsym;
     size_t L;
-    uint8_t *d_sym;                        // L raw symbols + zero padding
+    uint8_t *d_sym;                        // L raw symbols + zero padding (bytes, or 16-bit values when wide_raw)
+    bool wide_raw;                         // raw alphabet beyond 256 symbols
     std::shared_ptr<DictDev> dict;         // null: not compressed
     uint8_t *d_tok[imc::kNumLevels];       // token streams per level (aliases allowed), null if none
     bool wide[imc::kNumLevels];            // ... holding 16-bit ids (alphabets beyond 256)
@@ -258,15 +259,17 @@ void obs_release(imc_obs *o)
 // Build a chunk from validated host symbols.  Called WITHOUT g_mu: the O(L) host work (dictionary training, the
 // multi-level encoding: ~1.4 s at 1e8 columns) runs unlocked so that other threads keep evaluating; the lock is
 // taken only to read / publish the shared dictionary and for the HIP calls on the library's stream.
-int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
+int obs_upload(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym, imc_obs **out)
 {
+    // exactly one of host (alphabets up to 256: bytes) and host16 (larger alphabets) is non-null when L > 0
+    const bool wide_raw = nsym > imc::kByteAlphabet;
     std::shared_ptr<DictDev> dd;
     bool want_zip = false, train = false;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (int rc = ensure_ctx()) return rc;
         // ---- compression (the preprocess_raw_observations analogue, hmm.py:16) ----
-        want_zip = g.compression && L >= ZIP_MIN_COLUMNS && nsym <= 64;
+        want_zip = g.compression && L >= ZIP_MIN_COLUMNS && nsym < imc::kMaxAlphabet / 2;
         if (want_zip) {
             auto it = g.dicts.find(nsym);
             if (it != g.dicts.end()) dd = it->second;
@@ -275,13 +278,19 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
     }
     if (train) {                                        // host only, unlocked
         auto nd = std::make_shared<DictDev>();
-        const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
-        imc::train_dict(nd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64);
-        if (nd->dict.alphabet >= imc::kByteAlphabet) {   // 16-bit tokens: rounds over the whole chunk's byte-level stream
-            const size_t cols = std::min(L, DICT_WIDE_TRAIN_TOKENS * 96);   // a byte-level token covers ~60-100 columns
-            const std::vector<uint8_t> lvl256 = imc::encode_bytes(nd->dict, host, cols, nullptr);
-            const size_t nt = std::min(lvl256.size() - 1, DICT_WIDE_TRAIN_TOKENS);
-            imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), DICT_WIDE_MIN_COUNT);
+        if (wide_raw) {                                  // symbols are not bytes: straight to the 16-bit rounds on the raw stream
+            imc::init_dict(nd->dict, nsym);
+            const size_t nt = std::min(L - 1, DICT_WIDE_TRAIN_TOKENS * 8);
+            imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(host16 + 1, host16 + 1 + nt), DICT_WIDE_MIN_COUNT);
+        } else {
+            const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
+            imc::train_dict(nd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64);
+            if (nd->dict.alphabet >= imc::kByteAlphabet) {   // 16-bit tokens: rounds over the whole chunk's byte-level stream
+                const size_t cols = std::min(L, DICT_WIDE_TRAIN_TOKENS * 96);   // a byte-level token covers ~60-100 columns
+                const std::vector<uint8_t> lvl256 = imc::encode_bytes(nd->dict, host, cols, nullptr);
+                const size_t nt = std::min(lvl256.size() - 1, DICT_WIDE_TRAIN_TOKENS);
+                imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), DICT_WIDE_MIN_COUNT);
+            }
         }
         nd->depth.assign(nd->dict.alphabet, 0);
         for (int z = nsym; z < nd->dict.alphabet; ++z)
@@ -311,7 +320,7 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
     }
     imc::EncodedLevels enc;
     const bool zipped = dd && dd->dict.alphabet > nsym;
-    if (zipped) imc::encode_levels(dd->dict, host, L, enc);   // host only, unlocked (a published dictionary is immutable)
+    if (zipped) imc::encode_levels(dd->dict, host, host16, L, enc);   // host only, unlocked (a published dictionary is immutable)
 
     std::lock_guard<std::mutex> lk(g_mu);
     if (int rc = ensure_ctx()) return rc;
@@ -324,8 +333,10 @@ int obs_upload(const uint8_t *host, size_t L, int nsym, imc_obs **out)
     o->nsym = nsym;
     o->L = L;
     o->d_sym = nullptr;
+    o->wide_raw = wide_raw;
     for (int l = 0; l < imc::kNumLevels; ++l) { o->d_tok[l] = nullptr; o->wide[l] = false; o->ntok[l] = 0; o->alphabet[l] = nsym; }
-    hipError_t e = upload_padded(host, L, &o->d_sym);
+    hipError_t e = wide_raw ? upload_padded(reinterpret_cast<const uint8_t *>(host16), L * sizeof(imc::tok_t), &o->d_sym)
+                            : upload_padded(host, L, &o->d_sym);
     if (e != hipSuccess) {
         delete o;
         return fail(e == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
@@ -768,7 +779,7 @@ struct PlanBuilder {
                 gr.seglen = seg_vec;
                 // ... or the register-blocked kernel (one operator per 16-lane row): fill every row of the machine
                 // once; first segments waste 1 - 1/N of their row, which the cost comparison accounts for
-                if (kc->zip2 && g.kernel_pref != 1 && kc->blocked_lds(gr.A) <= LDS_BUDGET && (gr.zip || S == gr.A)) {
+                if (kc->zip2 && g.kernel_pref != 1 && kc->blocked_lds(gr.A) <= LDS_BUDGET && (gr.zip || (S == gr.A && S <= imc::kByteAlphabet))) {
                     size_t total = 0;
                     for (size_t L : lens) total += L;
                     const double rows = (double)g.cus * Z2WAVES * 4;
@@ -856,7 +867,7 @@ struct PlanBuilder {
             const size_t K0 = (L + gr.seglen - 1) / gr.seglen;
             const size_t sl = round_up((L + K0 - 1) / K0, 16);   // equalised, multiple of 16
             for (size_t off = 0, k = 0; off < L; off += sl, ++k) {
-                const bool wide = gr.zip && chunks[f]->wide[gr.level];
+                const bool wide = gr.zip ? chunks[f]->wide[gr.level] : chunks[f]->wide_raw;
                 const bool fst = k == 0 && !op_mode;   // operator mode: the chunk's own first segment is an operator too
                 segs.push_back(SegDesc{base + off * (wide ? 2 : 1), (uint32_t)std::min(sl, L - off),
                                        (fst ? SEG_FIRST : 0u) | (wide ? SEG_WIDE : 0u)});
@@ -1116,7 +1127,7 @@ int check_args(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, 
     if (n_chunks < 0 || (n_chunks > 0 && !chunks)) return fail(IMC_ERR_ARG, "chunks is null");
     if (B < 1) return fail(IMC_ERR_ARG, "B must be >= 1");
     if (N < 1) return fail(IMC_ERR_ARG, "N must be >= 1");
-    if (S < 1 || S > 256) return fail(IMC_ERR_ARG, "S must be in [1,256]");
+    if (S < 1 || S > imc::kMaxRawAlphabet) return fail(IMC_ERR_ARG, "S must be in [1," + std::to_string(imc::kMaxRawAlphabet) + "]");
     if (!pis || !Ts || !Es) return fail(IMC_ERR_ARG, "null parameter pointer");
     for (int f = 0; f < n_chunks; ++f) {
         if (!chunks[f]) return fail(IMC_ERR_ARG, "null chunk handle");
@@ -1475,38 +1486,47 @@ int imc_set_device(int device)
 int imc_obs_create(const uint8_t *sym, size_t L, int nsym, imc_obs **out)
 {
     if (!out) return fail(IMC_ERR_ARG, "out is null");
-    if (nsym < 1 || nsym > 256) return fail(IMC_ERR_ARG, "nsym must be in [1,256]");
+    if (nsym < 1 || nsym > 256) return fail(IMC_ERR_ARG, "nsym must be in [1,256] for byte symbols (larger alphabets: imc_obs_create_i32)");
     if (L && !sym) return fail(IMC_ERR_ARG, "sym is null");
     if (L >= (size_t)1 << 31) return fail(IMC_ERR_ARG, "chunk too long (limit 2^31-1 columns per chunk)");
     for (size_t t = 0; t < L; ++t)
         if (sym[t] >= nsym) return fail(IMC_ERR_SYMBOL, "symbol " + std::to_string(sym[t]) + " at column " + std::to_string(t) + " >= nsym");
-    return obs_upload(sym, L, nsym, out);
+    return obs_upload(sym, nullptr, L, nsym, out);
 }
 
 int imc_obs_create_i32(const int32_t *sym, size_t L, int nsym, imc_obs **out)
 {
     if (!out) return fail(IMC_ERR_ARG, "out is null");
-    if (nsym < 1 || nsym > 256) return fail(IMC_ERR_ARG, "nsym must be in [1,256]");
+    if (nsym < 1 || nsym > imc::kMaxRawAlphabet) return fail(IMC_ERR_ARG, "nsym must be in [1," + std::to_string(imc::kMaxRawAlphabet) + "]");
     if (L && !sym) return fail(IMC_ERR_ARG, "sym is null");
     if (L >= (size_t)1 << 31) return fail(IMC_ERR_ARG, "chunk too long (limit 2^31-1 columns per chunk)");
-    std::vector<uint8_t> tmp(L);
-    for (size_t t = 0; t < L; ++t) {
+    for (size_t t = 0; t < L; ++t)
         if (sym[t] < 0 || sym[t] >= nsym)
             return fail(IMC_ERR_SYMBOL, "symbol " + std::to_string(sym[t]) + " at column " + std::to_string(t) + " outside [0,nsym)");
-        tmp[t] = (uint8_t)sym[t];
+    if (nsym > imc::kByteAlphabet) {                    // e.g. the 257-symbol quartet alphabet (prepare-alignments.py:186-190)
+        std::vector<imc::tok_t> wide(sym, sym + L);
+        return obs_upload(nullptr, wide.data(), L, nsym, out);
     }
-    return obs_upload(tmp.data(), L, nsym, out);
+    std::vector<uint8_t> tmp(sym, sym + L);
+    return obs_upload(tmp.data(), nullptr, L, nsym, out);
 }
 
 int imc_obs_create_from_text(const char *path, int nsym, imc_obs **out)
 {
     if (!out || !path) return fail(IMC_ERR_ARG, "null argument");
-    if (nsym < 1 || nsym > 256) return fail(IMC_ERR_ARG, "nsym must be in [1,256]");
+    if (nsym < 1 || nsym > imc::kMaxRawAlphabet) return fail(IMC_ERR_ARG, "nsym must be in [1," + std::to_string(imc::kMaxRawAlphabet) + "]");
+    if (nsym > imc::kByteAlphabet) {
+        std::vector<imc::tok_t> wide;
+        const imc::IoResult rw = imc::read_observation_file(path, nsym, wide);
+        if (rw.code) return fail(rw.code, rw.msg);
+        if (wide.size() >= (size_t)1 << 31) return fail(IMC_ERR_ARG, "chunk too long (limit 2^31-1 columns per chunk)");
+        return obs_upload(nullptr, wide.data(), wide.size(), nsym, out);
+    }
     std::vector<uint8_t> sym;
     const imc::IoResult r = imc::read_observation_file(path, nsym, sym);
     if (r.code) return fail(r.code, r.msg);
     if (sym.size() >= (size_t)1 << 31) return fail(IMC_ERR_ARG, "chunk too long (limit 2^31-1 columns per chunk)");
-    return obs_upload(sym.data(), sym.size(), nsym, out);
+    return obs_upload(sym.data(), nullptr, sym.size(), nsym, out);
 }
 
 int imc_read_observations(const char *path, int nsym, uint8_t *sym_out, size_t capacity, size_t *length)

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_propagate(PropArgs a)
     const SegDesc sd = a.segs[vd.seg];
     const int len = (vid < a.n_vecs) ? (int)sd.len : 0;
     const bool first = (sd.first & SEG_FIRST) != 0;
+    const bool wide = (sd.first & SEG_WIDE) != 0;      // 16-bit symbols (raw alphabets beyond 256)
     const uint8_t *obs = sd.obs;
 
     double xo[R];
@@ -216,29 +217,41 @@ __global__ __launch_bounds__(WPB * 64, MINW) void k_propagate(PropArgs a)
     const int head_end = min(RESCALE_EVERY, maxlen);
     for (int t = 0; t < head_end; ++t) {
         const bool act = t < len;
-        const int sym = act ? (int)obs[t] : 0;
+        const int sym = act ? seg_token(obs, wide, t) : 0;
         column_step<R, NP, true, true>(xo, Tb, xw, own, Et, sym, act, first && t == 0, s);
         rescale<R>(xo, s, ex);
     }
     // ---- body: full 16-column blocks common to every vector of this wavefront ----
     for (int blk = 1; blk < nfull; ++blk) {
-        const uint4 ob = *reinterpret_cast<const uint4 *>(obs + (size_t)blk * RESCALE_EVERY);
-        uint32_t w0 = ob.x, w1 = ob.y, w2 = ob.z, w3 = ob.w;
+        // 16 symbols: one 16-byte load of bytes, or two of 16-bit values; either way the loop below sees four words
+        // of four symbols each, a symbol occupying SH = 8 or 16 bits of a 64-bit pair (per-lane, no divergence)
+        const uint4 *src = reinterpret_cast<const uint4 *>(obs + (size_t)blk * RESCALE_EVERY * (wide ? 2 : 1));
+        const uint4 oa = src[0];
+        const uint4 ob = wide ? src[1] : oa;
+        unsigned long long v0, v1, v2, v3;
+        if (wide) {
+            v0 = (unsigned long long)oa.y << 32 | oa.x; v1 = (unsigned long long)oa.w << 32 | oa.z;
+            v2 = (unsigned long long)ob.y << 32 | ob.x; v3 = (unsigned long long)ob.w << 32 | ob.z;
+        } else {
+            v0 = oa.x; v1 = oa.y; v2 = oa.z; v3 = oa.w;
+        }
+        const int sh = wide ? 16 : 8;
+        const unsigned mask = wide ? 0xffffu : 0xffu;
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
-            const uint32_t w = w0;
-            w0 = w1; w1 = w2; w2 = w3;
-            column_step<R, NP, false, false>(xo, Tb, xw, own, Et, w & 0xffu, true, false, s);
-            column_step<R, NP, false, false>(xo, Tb, xw, own, Et, (w >> 8) & 0xffu, true, false, s);
-            column_step<R, NP, false, false>(xo, Tb, xw, own, Et, (w >> 16) & 0xffu, true, false, s);
-            column_step<R, NP, false, true>(xo, Tb, xw, own, Et, w >> 24, true, false, s);
+            const unsigned long long w = v0;
+            v0 = v1; v1 = v2; v2 = v3;
+            column_step<R, NP, false, false>(xo, Tb, xw, own, Et, (int)((unsigned)w & mask), true, false, s);
+            column_step<R, NP, false, false>(xo, Tb, xw, own, Et, (int)((unsigned)(w >> sh) & mask), true, false, s);
+            column_step<R, NP, false, false>(xo, Tb, xw, own, Et, (int)((unsigned)(w >> (2 * sh)) & mask), true, false, s);
+            column_step<R, NP, false, true>(xo, Tb, xw, own, Et, (int)((unsigned)(w >> (3 * sh)) & mask), true, false, s);
         }
         rescale<R>(xo, s, ex);
     }
     // ---- tail: ragged remainder, column by column ----
     for (int t = max(RESCALE_EVERY, nfull * RESCALE_EVERY); t < maxlen; ++t) {
         const bool act = t < len;
-        const int sym = act ? (int)obs[t] : 0;
+        const int sym = act ? seg_token(obs, wide, t) : 0;
         column_step<R, NP, true, true>(xo, Tb, xw, own, Et, sym, act, false, s);
         rescale<R>(xo, s, ex);
     }

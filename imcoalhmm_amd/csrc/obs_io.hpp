@@ -2,7 +2,9 @@
 //
 //  * read_observation_file: the reference's text format (whitespace-separated decimal symbols, written by
 //    scripts/prepare-alignments.py:92-105 and read at src/IMCoalHMM/hmm.py:13-14) or this library's packed
-//    cache ("IMCOBS1\n" magic; 2 bits per column when nsym <= 4, else 1 byte per column);
+//    cache ("IMCOBS1\n" magic; 2 bits per column when nsym <= 4, 1 byte up to 256 symbols, 2 bytes beyond);
+//    templated on the symbol type: uint8_t for alphabets up to 256, uint16_t beyond (the ILS quartet alphabet of
+//    scripts/prepare-alignments.py:186-190 has 257 symbols);
 //  * encode_pairwise: the pairwise symbol rule of scripts/prepare-alignments.py:99-105
 //    (2 = either base not in ACGT, 0 = equal, 1 = different; case-insensitive);
 //  * write_cache.
@@ -32,8 +34,10 @@ inline IoResult io_fail(int code, const std::string &m)
     return r;
 }
 
-inline IoResult read_observation_file(const char *path, int nsym, std::vector<uint8_t> &sym)
+template <typename T>
+inline IoResult read_observation_file(const char *path, int nsym, std::vector<T> &sym)
 {
+    if (nsym > (sizeof(T) == 1 ? 256 : 65536)) return io_fail(-1, "alphabet too large for this symbol type");
     FILE *fp = std::fopen(path, "rb");
     if (!fp) return io_fail(-5, std::string("cannot open ") + path + ": " + std::strerror(errno));
     sym.clear();
@@ -47,7 +51,7 @@ inline IoResult read_observation_file(const char *path, int nsym, std::vector<ui
             std::fclose(fp);
             return io_fail(-5, std::string("truncated cache header in ") + path);
         }
-        if ((bits != 2 && bits != 8) || fs < 1 || fs > 256 || (bits == 2 && fs > 4)) {
+        if ((bits != 2 && bits != 8 && bits != 16) || fs < 1 || fs > 65536 || (bits == 2 && fs > 4) || (bits == 8 && fs > 256)) {
             std::fclose(fp);
             return io_fail(-5, std::string("bad cache header in ") + path);
         }
@@ -56,8 +60,11 @@ inline IoResult read_observation_file(const char *path, int nsym, std::vector<ui
             return io_fail(-2, "cache holds an alphabet of " + std::to_string(fs) + " symbols, more than nsym");
         }
         sym.resize(L);
-        if (bits == 8) {
-            if (L && std::fread(sym.data(), 1, L, fp) != L) { std::fclose(fp); return io_fail(-5, std::string("truncated cache ") + path); }
+        if (bits == 8 || bits == 16) {
+            const size_t w = bits / 8;
+            std::vector<uint8_t> raw(L * w);
+            if (L && std::fread(raw.data(), 1, raw.size(), fp) != raw.size()) { std::fclose(fp); return io_fail(-5, std::string("truncated cache ") + path); }
+            for (uint64_t t = 0; t < L; ++t) sym[t] = (T)(w == 1 ? raw[t] : (uint16_t)(raw[2 * t] | raw[2 * t + 1] << 8));
         } else {
             std::vector<uint8_t> pk((L + 3) / 4);
             if (!pk.empty() && std::fread(pk.data(), 1, pk.size(), fp) != pk.size()) { std::fclose(fp); return io_fail(-5, std::string("truncated cache ") + path); }
@@ -86,7 +93,7 @@ inline IoResult read_observation_file(const char *path, int nsym, std::vector<ui
                         std::fclose(fp);
                         return io_fail(-2, "symbol " + std::to_string(cur) + " at column " + std::to_string(sym.size()) + " >= nsym");
                     }
-                    sym.push_back((uint8_t)cur);
+                    sym.push_back((T)cur);
                     cur = -1;
                 }
             } else {
@@ -99,21 +106,29 @@ inline IoResult read_observation_file(const char *path, int nsym, std::vector<ui
     std::fclose(fp);
     if (cur >= 0) {
         if (cur >= nsym) return io_fail(-2, "symbol " + std::to_string(cur) + " >= nsym");
-        sym.push_back((uint8_t)cur);
+        sym.push_back((T)cur);
     }
     return IoResult();
 }
 
-inline IoResult write_cache(const char *path, const uint8_t *sym, uint64_t L, int nsym)
+template <typename T>
+inline IoResult write_cache(const char *path, const T *sym, uint64_t L, int nsym)
 {
     for (uint64_t t = 0; t < L; ++t)
         if (sym[t] >= nsym) return io_fail(-2, "symbol " + std::to_string(sym[t]) + " at column " + std::to_string(t) + " >= nsym");
     FILE *fp = std::fopen(path, "wb");
     if (!fp) return io_fail(-5, std::string("cannot create ") + path + ": " + std::strerror(errno));
-    const uint32_t fs = (uint32_t)nsym, bits = nsym <= 4 ? 2u : 8u;
+    const uint32_t fs = (uint32_t)nsym, bits = nsym <= 4 ? 2u : nsym <= 256 ? 8u : 16u;
     bool ok = std::fwrite(kCacheMagic, 1, 8, fp) == 8 && std::fwrite(&fs, 4, 1, fp) == 1 && std::fwrite(&bits, 4, 1, fp) == 1 &&
               std::fwrite(&L, 8, 1, fp) == 1;
-    if (ok && bits == 8 && L) ok = std::fwrite(sym, 1, L, fp) == L;
+    if (ok && bits >= 8 && L) {
+        std::vector<uint8_t> raw(L * (bits / 8));
+        for (uint64_t t = 0; t < L; ++t) {
+            if (bits == 8) raw[t] = (uint8_t)sym[t];
+            else { raw[2 * t] = (uint8_t)(sym[t] & 0xff); raw[2 * t + 1] = (uint8_t)((uint32_t)sym[t] >> 8); }
+        }
+        ok = std::fwrite(raw.data(), 1, raw.size(), fp) == raw.size();
+    }
     if (ok && bits == 2) {
         std::vector<uint8_t> pk((L + 3) / 4, 0);
         for (uint64_t t = 0; t < L; ++t) pk[t >> 2] |= (uint8_t)(sym[t] << (2 * (t & 3)));

@@ -37,6 +37,9 @@ constexpr int kLevels[] = {8,   12,  16,   24,   32,   44,   64,   96,   128,  1
 constexpr int kNumLevels = 23;
 constexpr int kByteAlphabet = 256;   // levels up to here: one merge per pass, byte streams
 constexpr int kMaxAlphabet = 16384;
+constexpr int kMaxRawAlphabet = 4096;   // largest raw alphabet S (symbols beyond 255 travel as 16-bit values)
+// first token id found in rounds: 256 for byte-sized raw alphabets, the raw alphabet itself beyond
+constexpr int wide_base(int nsym) { return nsym > kByteAlphabet ? nsym : kByteAlphabet; }
 // merges per round beyond kByteAlphabet: 64 up to 1024 tokens, 256 from there (every wide level is a round boundary)
 constexpr int round_size(int first_token) { return first_token < 1024 ? 64 : 256; }
 
@@ -140,11 +143,22 @@ inline void radix_sort_u32(std::vector<uint32_t> &keys, std::vector<uint32_t> &s
     }
 }
 
-// Phase 2: extend a full byte dictionary in rounds on `seq`, the byte-level token stream of the training
-// chunk (first column removed).  A pair needs `min_count` occurrences to become a token.
+// A dictionary with no merges yet (raw alphabets beyond 256 symbols skip phase 1: their symbols are not bytes).
+inline void init_dict(PairDict &d, int nsym)
+{
+    d.nsym = nsym;
+    d.alphabet = nsym;
+    d.left.assign(nsym, 0);
+    d.right.assign(nsym, 0);
+    d.span.assign(nsym, 1);
+}
+
+// Phase 2: extend a full byte dictionary (or the bare raw alphabet when that has more than 256 symbols) in rounds on
+// `seq`, the byte-level token stream (raw stream) of the training chunk, first column removed.  A pair needs
+// `min_count` occurrences to become a token.
 inline void train_dict_wide(PairDict &d, std::vector<tok_t> seq, size_t min_count)
 {
-    if (d.alphabet < kByteAlphabet) return;
+    if (d.alphabet < wide_base(d.nsym)) return;
     size_t n = seq.size();
     std::vector<uint32_t> keys, scratch;
     while (d.alphabet < kMaxAlphabet && n >= 2) {
@@ -222,15 +236,27 @@ inline std::vector<uint8_t> encode_bytes(const PairDict &d, const uint8_t *obs, 
     return seq;
 }
 
-// Encode a chunk with a fixed dictionary: apply the merges in order, snapshot at every level.
-inline void encode_levels(const PairDict &d, const uint8_t *obs, size_t L, EncodedLevels &out)
+// Encode a chunk with a fixed dictionary: apply the merges in order, snapshot at every level.  The raw symbols come
+// as bytes (`obs`, alphabets up to 256) or as 16-bit values (`obs16`, larger alphabets: no byte levels exist then).
+inline void encode_levels(const PairDict &d, const uint8_t *obs, const tok_t *obs16, size_t L, EncodedLevels &out)
 {
-    const std::vector<uint8_t> bytes = encode_bytes(d, obs, L, &out);
+    std::vector<uint8_t> bytes;
+    std::vector<tok_t> seq;
     int lvl = 0;
-    while (lvl < kNumLevels && kLevels[lvl] <= kByteAlphabet) ++lvl;
-    std::vector<tok_t> seq(bytes.begin(), bytes.end());
+    if (obs16) {
+        for (; lvl < kNumLevels && kLevels[lvl] <= kByteAlphabet; ++lvl) {   // not larger than the raw alphabet: the raw stream
+            out.alphabet[lvl] = d.nsym;
+            out.length[lvl] = L;
+            out.is_wide[lvl] = true;
+        }
+        seq.assign(obs16, obs16 + L);
+    } else {
+        bytes = encode_bytes(d, obs, L, &out);
+        while (lvl < kNumLevels && kLevels[lvl] <= kByteAlphabet) ++lvl;
+        seq.assign(bytes.begin(), bytes.end());
+    }
     size_t n = seq.size();
-    for (int z0 = kByteAlphabet; z0 < d.alphabet; z0 += round_size(z0)) {
+    for (int z0 = wide_base(d.nsym); z0 < d.alphabet; z0 += round_size(z0)) {
         const int z1 = std::min(z0 + round_size(z0), d.alphabet);
         std::vector<uint32_t> rk;
         std::vector<tok_t> ri;
@@ -240,8 +266,10 @@ inline void encode_levels(const PairDict &d, const uint8_t *obs, size_t L, Encod
         }
         if (n > 2) n = 1 + replace_round(seq.data() + 1, n - 1, rk, ri);
         while (lvl < kNumLevels && kLevels[lvl] <= z1) {
+            // the stream now holds every token below z1 (with 256-symbol-or-smaller raw alphabets the rounds end
+            // exactly on the level sizes; beyond, a level is the first round end that reaches it)
             out.wide[lvl].assign(seq.begin(), seq.begin() + n);
-            out.alphabet[lvl] = kLevels[lvl];
+            out.alphabet[lvl] = z1;
             out.length[lvl] = n;
             out.is_wide[lvl] = true;
             ++lvl;

@@ -13,7 +13,9 @@
  *   Every chunk (alignment file) restarts from pi and chunk log-likelihoods are summed
  *   left-to-right starting from 0.0 (likelihood.py:33).
  *   A zero-probability sequence yields -inf (not an error); NaN in -> NaN out.
- *   Limits: N <= 256 states, S <= 256 symbols, < 2^31 columns per chunk, and |log-likelihood| of one chunk
+ *   Limits: N <= 256 states, S <= 4096 symbols (alphabets beyond 256, e.g. the 257-symbol quartet alphabet of
+ *   scripts/prepare-alignments.py:186-190, go through imc_obs_create_i32 / imc_obs_create_from_text and are kept as
+ *   16-bit symbols), < 2^31 columns per chunk, and |log-likelihood| of one chunk
  *   below ~1.4e9 nats (the power-of-two exponents of a chunk are summed in int32).
  *
  * Ownership: input buffers are borrowed for the duration of the call only.  Observations are

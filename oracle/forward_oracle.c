@@ -69,6 +69,38 @@ double orc_forward_scaled(int N, int S, const double *pi, const double *T, const
     return ll;
 }
 
+/* The same recursion for observations given as 16-bit symbols (alphabets beyond 256 symbols, e.g. the 257-symbol
+ * quartet alphabet of scripts/prepare-alignments.py:186-190); statement for statement the function above. */
+double orc_forward_scaled_u16(int N, int S, const double *pi, const double *T, const double *E,
+                              const uint16_t *obs, size_t L)
+{
+    if (L == 0) return 0.0;
+    double *a = (double *)malloc(sizeof(double) * 2 * (size_t)N);
+    double *b = a + N;
+    double ll = 0.0, c = 0.0;
+    for (int j = 0; j < N; ++j) { a[j] = pi[j] * E[(size_t)j * S + obs[0]]; c += a[j]; }
+    if (!(c > 0.0)) { free(a); return (c == 0.0) ? -INFINITY : NAN; }
+    for (int j = 0; j < N; ++j) a[j] /= c;
+    ll += log(c);
+    for (size_t t = 1; t < L; ++t) {
+        const int o = obs[t];
+        for (int j = 0; j < N; ++j) b[j] = 0.0;
+        for (int i = 0; i < N; ++i) {
+            const double ai = a[i];
+            const double *Ti = T + (size_t)i * N;
+            for (int j = 0; j < N; ++j) b[j] += Ti[j] * ai;
+        }
+        c = 0.0;
+        for (int j = 0; j < N; ++j) { b[j] *= E[(size_t)j * S + o]; c += b[j]; }
+        if (!(c > 0.0)) { free(a); return (c == 0.0) ? -INFINITY : NAN; }
+        const double r = 1.0 / c;
+        for (int j = 0; j < N; ++j) a[j] = b[j] * r;
+        ll += log(c);
+    }
+    free(a);
+    return ll;
+}
+
 /* Same recursion in long double with a compensated (Neumaier) log accumulator: the spot-check
  * arbiter for the fp64 implementations. */
 double orc_forward_scaled_ld(int N, int S, const double *pi, const double *T, const double *E,

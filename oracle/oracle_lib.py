@@ -30,6 +30,9 @@ def lib():
             f = getattr(L, name)
             f.restype = ctypes.c_double
             f.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _u8p, ctypes.c_size_t]
+        L.orc_forward_scaled_u16.restype = ctypes.c_double
+        L.orc_forward_scaled_u16.argtypes = [ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, ctypes.POINTER(ctypes.c_uint16),
+                                             ctypes.c_size_t]
         L.orc_zip_preprocess.restype = ctypes.c_void_p
         L.orc_zip_preprocess.argtypes = [_u8p, ctypes.c_size_t, ctypes.c_int, ctypes.c_long, ctypes.c_int]
         L.orc_zip_length.restype = ctypes.c_size_t
@@ -65,6 +68,15 @@ def _p(a):
 
 
 def forward_scaled(pi, T, E, obs):
+    if np.asarray(E).shape[1] > 256:                     # alphabets beyond 256 symbols: 16-bit observations
+        pi = np.ascontiguousarray(pi, dtype=np.float64).reshape(-1)
+        T = np.ascontiguousarray(T, dtype=np.float64)
+        E = np.ascontiguousarray(E, dtype=np.float64)
+        obs = np.asarray(obs)
+        assert obs.size == 0 or (int(obs.min()) >= 0 and int(obs.max()) < E.shape[1])
+        obs = np.ascontiguousarray(obs, dtype=np.uint16)
+        return lib().orc_forward_scaled_u16(E.shape[0], E.shape[1], _p(pi), _p(T), _p(E),
+                                            obs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), obs.size)
     pi, T, E, obs, N, S = _prep(pi, T, E, obs)
     return lib().orc_forward_scaled(N, S, _p(pi), _p(T), _p(E), obs.ctypes.data_as(_u8p), obs.size)
 

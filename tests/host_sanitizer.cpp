@@ -21,7 +21,7 @@ int main() {
         }
         if ((int)d.left.size() != d.alphabet || (int)d.right.size() != d.alphabet) { std::printf("dictionary size\n"); return 1; }
         imc::EncodedLevels enc;
-        imc::encode_levels(d, obs.data(), L, enc);
+        imc::encode_levels(d, obs.data(), nullptr, L, enc);
         // decode each level and compare
         for (int l = 0; l < imc::kNumLevels; ++l) {
             std::vector<uint8_t> out;
@@ -49,6 +49,57 @@ int main() {
         if (r.code || r2.code || back != obs) { std::printf("cache mismatch\n"); return 1; }
     }
     if (!wide_levels) { std::printf("the 16-bit dictionary phase never ran\n"); return 1; }
+    // Raw alphabets of 65, 200, 256 (bytes) and 257, 1000 (16-bit symbols, no byte phase): train, encode every level,
+    // decode it back; 16-bit cache round trip.
+    int merged_levels = 0;
+    for (int nsym : {65, 200, 256, 257, 1000}) {
+        const size_t L = 400000;
+        std::vector<imc::tok_t> obs(L);
+        for (auto &x : obs) x = (imc::tok_t)((rng() % 100 < 90) ? (rng() % 3) * (nsym / 3) : rng() % nsym);
+        obs[7] = (imc::tok_t)(nsym - 1);
+        std::vector<uint8_t> obs8(obs.begin(), obs.end());
+        const bool wide_raw = nsym > imc::kByteAlphabet;
+        imc::PairDict d;
+        if (wide_raw) {
+            imc::init_dict(d, nsym);
+            imc::train_dict_wide(d, std::vector<imc::tok_t>(obs.begin() + 1, obs.end()), 3);
+        } else {
+            imc::train_dict(d, nsym, std::vector<uint8_t>(obs8.begin() + 1, obs8.end()), 4);
+            if (d.alphabet >= imc::kByteAlphabet) {
+                const std::vector<uint8_t> b = imc::encode_bytes(d, obs8.data(), L, nullptr);
+                imc::train_dict_wide(d, std::vector<imc::tok_t>(b.begin() + 1, b.end()), 3);
+            }
+        }
+        if (d.alphabet <= nsym) { std::printf("no merges at nsym %d\n", nsym); return 1; }
+        imc::EncodedLevels enc;
+        imc::encode_levels(d, wide_raw ? nullptr : obs8.data(), wide_raw ? obs.data() : nullptr, L, enc);
+        for (int l = 0; l < imc::kNumLevels; ++l) {
+            if (enc.alphabet[l] > d.alphabet || enc.alphabet[l] < nsym) { std::printf("level alphabet (nsym %d level %d)\n", nsym, l); return 1; }
+            if (enc.alphabet[l] <= nsym) continue;                       // the raw stream itself
+            ++merged_levels;
+            std::vector<imc::tok_t> out;
+            std::vector<int> stack;
+            if (l > 0 && enc.length[l] > enc.length[l - 1]) { std::printf("levels must not grow\n"); return 1; }
+            for (size_t q = 0; q < enc.length[l]; ++q) {
+                const int t = enc.is_wide[l] ? (int)enc.wide[l][q] : (int)enc.bytes[l][q];
+                if (t >= enc.alphabet[l]) { std::printf("token out of alphabet (nsym %d level %d)\n", nsym, l); return 1; }
+                stack.assign(1, t);
+                while (!stack.empty()) {
+                    const int z = stack.back(); stack.pop_back();
+                    if (z < nsym) out.push_back((imc::tok_t)z);
+                    else { stack.push_back(d.right[z]); stack.push_back(d.left[z]); }
+                }
+            }
+            if (out != obs) { std::printf("MISMATCH nsym %d level %d\n", nsym, l); return 1; }
+        }
+        const char *path = "imc_sanitizer_tmp16.imc";
+        std::vector<imc::tok_t> back;
+        auto w = imc::write_cache(path, obs.data(), L, nsym);
+        auto rr = imc::read_observation_file(path, nsym, back);
+        if (w.code || rr.code || back != obs) { std::printf("16-bit cache mismatch\n"); return 1; }
+        std::remove(path);
+    }
+    if (merged_levels < 10) { std::printf("large alphabets produced too few merged levels\n"); return 1; }
     std::printf("sanitizer run ok\n");
     return 0;
 }

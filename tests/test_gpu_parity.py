@@ -554,3 +554,57 @@ def test_rank_one_handoff(oracle, n, stay):
         for k, c in enumerate(chunks):
             want = oracle.forward_scaled(pis[b], Ts[b], Es[b], c)
             assert rel_err(got[b][k], want) < TOL, (n, stay, b, k, got[b][k], want)
+
+
+def _skewed_symbols(n, nsym, seed):
+    """A compressible stream over a large alphabet: three frequent symbols (one of them the last), the rest rare."""
+    rng = np.random.default_rng(seed)
+    hot = np.array([0, nsym // 2, nsym - 1])
+    obs = np.where(rng.random(n) < 0.9, hot[rng.integers(0, 3, size=n)], rng.integers(0, nsym, size=n))
+    return obs.astype(np.int32)
+
+
+@pytest.mark.parametrize("nsym", [65, 257])
+@pytest.mark.parametrize("n", [10, 20, 40, 150])
+def test_ils_sized_alphabets(oracle, n, nsym):
+    """the triplet (65) and quartet (257 symbols, scripts/prepare-alignments.py:142-146,
+    186-190) alphabets of the ILS model.  Symbol 256 needs 16-bit observations; chunks this long are pair-compressed
+    whatever the alphabet (byte tokens for 65 symbols, 16-bit rounds for both), and the raw stream is evaluated too."""
+    pi, T, E = synth.random_hmm(n, nsym, seed=1000 + n + nsym, stay=0.95)
+    chunks = [_skewed_symbols(m, nsym, seed=n + nsym + k) for k, m in enumerate((60_000, 1, 4099, 33))]
+    want = [oracle.forward_scaled(pi, T, E, c) for c in chunks]
+    try:
+        for mode in (1, 0):
+            set_zip(mode)
+            fw = [Forwarder.from_array(c, nsym) for c in chunks]
+            if mode == 1:
+                ntok, alpha = fw[0].compressed_length(16384)
+                assert alpha > nsym and ntok * 2 < len(chunks[0]), (ntok, alpha)     # the long chunk did compress
+            for seg in (0, 256):
+                set_seg(seg)
+                per = forward_chunks_batch([f.handle for f in fw], pi[None], T[None], E[None], per_chunk=True)[0]
+                for g, w in zip(per, want):
+                    assert rel_err(g, w) < TOL, (n, nsym, mode, seg, g, w, _capi.last_plan()["kernels"])
+            set_seg(0)
+            if mode == 1 and n > 64:
+                assert "tokens" in _capi.last_plan()["kernels"]                     # the global-table kernels (N > 64) run on the tokens
+    finally:
+        set_seg(0)
+        set_zip(1)
+
+
+def test_quartet_alphabet_text_file_and_errors(tmp_path, oracle):
+    """The 257-symbol alphabet through the reference's constructor (text file, hmm.py:12-16) and the API's limits."""
+    nsym, n = 257, 12
+    pi, T, E = synth.random_hmm(n, nsym, seed=3, stay=0.9)
+    obs = _skewed_symbols(5000, nsym, seed=9)
+    path = tmp_path / "quartet.txt"
+    path.write_text(" ".join(str(int(s)) for s in obs) + " ")
+    got = Forwarder(str(path), NSYM=nsym).forward(pi, T, E)
+    assert rel_err(got, oracle.forward_scaled(pi, T, E, obs)) < TOL
+    with pytest.raises(ValueError):
+        Forwarder.from_array(np.array([0, 257], dtype=np.int32), nsym)              # symbol out of range
+    with pytest.raises(ValueError):
+        Forwarder.from_array(np.zeros(4, dtype=np.uint8), 300)                        # bytes cannot carry 300 symbols
+    with pytest.raises(ValueError):
+        Forwarder.from_array(np.zeros(4, dtype=np.int32), 5000)                       # beyond the library's limit
