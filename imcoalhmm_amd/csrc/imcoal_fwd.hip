@@ -469,6 +469,9 @@ struct Group {             // one propagate launch
     BigBlock *d_big_blocks = nullptr;
     uint32_t *d_seg_ids = nullptr, *d_seg_out = nullptr;
     Z2Block *d_blocks = nullptr;
+    uint16_t *d_tab_order = nullptr;          // blocked MFMA kernel: merged tokens of the alphabet by dictionary depth
+    int *d_tab_lvl = nullptr;
+    int tab_nlvl = 0;
     double *d_Ctab = nullptr;
     int *d_cex = nullptr;
     // rank-one hand-off (GEMM chain only): operator segments run on the GEMM chain in rounds that end at the
@@ -537,7 +540,7 @@ struct Plan {
         if (graph) (void)hipGraphExecDestroy(graph);
         dev_free(d_segs); dev_free(d_vecs); dev_free(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
+        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
         dev_free(d_params); dev_free(d_out);
         for (int k = 0; k < 2; ++k) { (void)hipHostFree(h_params[k]); if (ev_params[k]) (void)hipEventDestroy(ev_params[k]); }
         (void)hipHostFree(h_out);
@@ -1001,6 +1004,25 @@ struct PlanBuilder {
         }
         for (Group &gr : q->groups) {
             if (gr.zip2 && e == hipSuccess) e = up((void **)&gr.d_blocks, gr.blocks.data(), gr.blocks.size() * sizeof(Z2Block));
+            if (gr.zip2 && gr.zip && e == hipSuccess) {
+                // merged tokens of this level's alphabet (ids S .. A-1) grouped by dictionary depth, for the table build
+                const DictDev &dd = *gr.dict;
+                std::vector<uint16_t> order;
+                std::vector<int> lvl(1, 0);
+                int cur = -1;
+                for (uint16_t z : dd.order) {                       // (sorted by depth, then id)
+                    if ((int)z >= gr.A) continue;
+                    if (dd.depth[z] != cur) {
+                        if (cur >= 0) lvl.push_back((int)order.size());
+                        cur = dd.depth[z];
+                    }
+                    order.push_back(z);
+                }
+                lvl.push_back((int)order.size());
+                gr.tab_nlvl = order.empty() ? 0 : (int)lvl.size() - 1;
+                e = up((void **)&gr.d_tab_order, order.data(), order.size() * sizeof(uint16_t));
+                if (e == hipSuccess) e = up((void **)&gr.d_tab_lvl, lvl.data(), lvl.size() * sizeof(int));
+            }
             if (!gr.big || e != hipSuccess) continue;
             const size_t np2 = (size_t)kc->NP * kc->NP;
             // workgroup list: slabs of one segment 8 ids apart (same XCD -> they share the operator rows in L2)
@@ -1204,6 +1226,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.phase = gr.rank1 ? 1 : 0; ba.t_from = 0; ba.t_to = gr.rank1 ? gr.checkpoints[0] : INT_MAX;
             ba.r1flag = gr.d_r1flag; ba.r1at = gr.d_r1at; ba.r1u = gr.d_r1u;
             ba.r1alpha = gr.d_r1alpha; ba.n_segs = p->n_segs;
+            ba.tab_order = nullptr; ba.tab_lvl = nullptr; ba.tab_nlvl = 0;
             if (gr.rank1) HIP_TRY(hipMemsetAsync(gr.d_r1flag, 0, (size_t)B * p->n_segs * 4, stream));   // nothing certified yet
             hipLaunchKernelGGL(kc->big_table_raw, dim3((unsigned)S, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
@@ -1283,6 +1306,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
             ba.Ctab = nullptr; ba.cex = nullptr;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
+            ba.tab_order = gr.d_tab_order; ba.tab_lvl = gr.d_tab_lvl; ba.tab_nlvl = gr.tab_nlvl;
             const bool v3 = kc->use3();
             bool &attr_set = v3 ? kc->zip3_attr_set : kc->zip2_attr_set;
             if (!attr_set) {

@@ -50,6 +50,11 @@ struct BigArgs {
     int *r1at;                    // [B][n_segs] token count at which that was certified (the tail starts there)
     double *r1u, *r1alpha;        // [B][n_segs][NP] its column direction u and column scales alpha
     uint32_t n_segs;
+    // k_zpropagate3's table build: the merged tokens of this launch's alphabet sorted by dictionary depth, tokens of
+    // depth d at tab_order[tab_lvl[d] .. tab_lvl[d+1]) - a token only depends on tokens of smaller depth
+    const uint16_t *tab_order;
+    const int *tab_lvl;
+    int tab_nlvl;
 };
 
 
