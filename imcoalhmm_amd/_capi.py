@@ -43,6 +43,12 @@ SIGNATURES = [
     ("imc_obs_length", ctypes.c_size_t, [ctypes.c_void_p]),
     ("imc_obs_nsym", ctypes.c_int, [ctypes.c_void_p]),
     ("imc_obs_compressed_length", ctypes.c_size_t, [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
+    ("imc_obs_dictionary", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint16), ctypes.POINTER(ctypes.c_uint16), ctypes.c_size_t,
+      ctypes.POINTER(ctypes.c_int)]),
+    ("imc_obs_tokens", ctypes.c_int,
+     [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint16), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+      ctypes.POINTER(ctypes.c_int)]),
     ("imc_obs_free", ctypes.c_int, [ctypes.c_void_p]),
     ("imc_forward", ctypes.c_int, [_vpp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _dp, _dp, _dp, _dp]),
     ("imc_forward_batch", ctypes.c_int,

@@ -72,6 +72,7 @@ constexpr size_t DICT_TRAIN_MAX = 8u << 20;        // byte tokens (< 256): train
 constexpr size_t DICT_WIDE_TRAIN_TOKENS = 1u << 19; // 16-bit tokens: train on at most this many byte-level tokens (~4e7 columns)
 constexpr size_t DICT_WIDE_MIN_COUNT = 6;          // ... in which a pair must occur this often
 constexpr size_t CTAB_BUDGET = (size_t)24 << 30;   // largest operator table (all parameter sets) a plan may allocate
+constexpr size_t Z2GRAN = 4;                       // blocked kernels: segment lengths are multiples of this many tokens
 constexpr size_t R1_MIN_SEGLEN = 1024;             // rank-one hand-off: segments at least this long (stream elements) ...
 constexpr size_t R1_MIN_HEAD = 256;                // ... run at least this many on the GEMM chain before the test
 constexpr double R1_HEAD_COLUMNS = 65536.0;        // planner's estimate of the columns a head needs before it collapses
@@ -800,8 +801,10 @@ struct PlanBuilder {
                     };
                     for (int rounds = 1; rounds <= 16; ++rounds) {               // fill the machine's rows `rounds` times
                         const double target = std::max((double)Z2SLOTS, std::floor(rows * rounds / B));
-                        size_t sg = std::max<size_t>(16, round_up((size_t)std::ceil((double)total / target), 16));
-                        for (int it = 0; it < 256 && rows_used(sg) > target; ++it) sg += 16;
+                        // (the blocked kernels take segments of any multiple of 4 tokens - dword-aligned 16-byte
+                        // loads - so the machine's rows can be filled to within a per cent, not to within 16 tokens)
+                        size_t sg = std::max<size_t>(16, round_up((size_t)std::ceil((double)total / target), Z2GRAN));
+                        for (int it = 0; it < 1024 && rows_used(sg) > target; ++it) sg += Z2GRAN;
                         const double used = rows_used(sg);
                         // per round of workgroups: the main loop, plus the table rebuild and the 5-level in-kernel fold
                         const double fixed = (double)(gr.A - S) * (400.0 + (double)kc->NP * kc->NP * kc->NP / 64.0)
@@ -868,7 +871,8 @@ struct PlanBuilder {
             const uint8_t *base = gr.zip ? chunks[f]->d_tok[gr.level] : chunks[f]->d_sym;
             if (!L) continue;
             const size_t K0 = (L + gr.seglen - 1) / gr.seglen;
-            const size_t sl = round_up((L + K0 - 1) / K0, 16);   // equalised, multiple of 16
+            const size_t sl = round_up((L + K0 - 1) / K0, gr.zip2 ? Z2GRAN : 16);   // equalised; a multiple of 16 (16-byte aligned
+                                                                                   // loads) except for the blocked kernels
             for (size_t off = 0, k = 0; off < L; off += sl, ++k) {
                 const bool wide = gr.zip ? chunks[f]->wide[gr.level] : chunks[f]->wide_raw;
                 const bool fst = k == 0 && !op_mode;   // operator mode: the chunk's own first segment is an operator too
@@ -1593,6 +1597,49 @@ size_t imc_obs_compressed_length(const imc_obs *obs, int alphabet_limit, int *al
             if (obs->alphabet[l] <= alphabet_limit && obs->alphabet[l] > obs->nsym && obs->d_tok[l]) { n = obs->ntok[l]; used = obs->alphabet[l]; }
     if (alphabet_used) *alphabet_used = used;
     return n;
+}
+
+int imc_obs_dictionary(const imc_obs *obs, int alphabet_limit, uint16_t *left, uint16_t *right, size_t capacity, int *alphabet_used)
+{
+    if (!obs || !alphabet_used) return fail(IMC_ERR_ARG, "null argument");
+    int used = obs->nsym;
+    if (obs->dict)
+        for (int l = 0; l < imc::kNumLevels; ++l)
+            if (obs->alphabet[l] <= alphabet_limit && obs->alphabet[l] > obs->nsym && obs->d_tok[l]) used = obs->alphabet[l];
+    *alphabet_used = used;
+    if ((left || right) && capacity < (size_t)(used - obs->nsym)) return fail(IMC_ERR_ARG, "capacity smaller than the number of merged tokens");
+    for (int z = obs->nsym; z < used; ++z) {
+        if (left) left[z - obs->nsym] = obs->dict->dict.left[z];
+        if (right) right[z - obs->nsym] = obs->dict->dict.right[z];
+    }
+    return IMC_OK;
+}
+
+int imc_obs_tokens(const imc_obs *obs, int alphabet_limit, uint16_t *tokens, size_t capacity, size_t *length, int *alphabet_used)
+{
+    if (!obs || !length) return fail(IMC_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (obs->pid != getpid()) return fail(IMC_ERR_ARG, "chunk handle was created in another process");
+    int level = -1, used = obs->nsym;
+    if (obs->dict)
+        for (int l = 0; l < imc::kNumLevels; ++l)
+            if (obs->alphabet[l] <= alphabet_limit && obs->alphabet[l] > obs->nsym && obs->d_tok[l]) { level = l; used = obs->alphabet[l]; }
+    const size_t n = level >= 0 ? obs->ntok[level] : obs->L;
+    *length = n;
+    if (alphabet_used) *alphabet_used = used;
+    if (!tokens) return IMC_OK;
+    if (capacity < n) return fail(IMC_ERR_ARG, "capacity smaller than the stream");
+    if (int rc = ensure_ctx()) return rc;
+    HIP_TRY(hipSetDevice(obs->device));
+    const bool wide = level >= 0 ? obs->wide[level] : obs->wide_raw;
+    const uint8_t *src = level >= 0 ? obs->d_tok[level] : obs->d_sym;
+    if (wide) HIP_TRY(hipMemcpy(tokens, src, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    else {
+        std::vector<uint8_t> tmp(n);
+        if (n) HIP_TRY(hipMemcpy(tmp.data(), src, n, hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < n; ++t) tokens[t] = tmp[t];
+    }
+    return IMC_OK;
 }
 
 int imc_obs_free(imc_obs *obs)

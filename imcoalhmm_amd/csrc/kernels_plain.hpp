@@ -28,7 +28,7 @@ __device__ __forceinline__ int dpp_i32(int x)
 static constexpr int DPP_ROW_ROR1 = 0x121, DPP_ROW_ROR2 = 0x122, DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128, DPP_ROW_ROR12 = 0x12c;
 
 struct SegDesc {          // one segment of one chunk
-    const uint8_t *obs;   // first column of the segment (16-byte aligned, padded past the end)
+    const uint8_t *obs;   // first column of the segment (16-byte aligned - 4-byte for the blocked kernels -, padded past the end)
     uint32_t len;         // columns in this segment
     uint32_t first;       // bit 0: first segment of its chunk (single vector, starts from pi); bit 1: 16-bit tokens
 };

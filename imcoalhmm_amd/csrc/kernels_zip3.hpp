@@ -212,20 +212,33 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
     int ex = 0;
     const int maxlen = wave_max_i32(len);
     const int nfull = maxlen == 0 ? 0 : wave_min_i32(valid ? len / RESCALE_EVERY : INT_MAX);   // idle wavefronts still join the fold's barriers
-    // token t of this lane's segment, or the identity where the segment has none (token 0 of a first segment went into
-    // the initial P)
-    auto tok_at = [&](int t) { return (t < len && !(first && t == 0)) ? (int)tokp[t] : IDENT; };
-    // a step pair; `a` carries the prefetched first tile-row of t0's operator in and of tn's operator out
+    // a step pair; `arow` carries the prefetched first tile-row of t0's operator in and of tn's operator out
     double arow[NT];
-    auto two_steps = [&](int t0, int t1, int tn) {
+    auto two_steps = [&](int t0, int t1, int tn) __attribute__((always_inline)) {
         zip3_step<NT>(P, Q, C + (size_t)t0 * TOK, C + (size_t)t1 * TOK, arow, lo, lx);
         zip3_step<NT>(Q, P, C + (size_t)t1 * TOK, C + (size_t)tn * TOK, arow, lo, lx);
         ex += cex[t0] + cex[t1];
     };
-    const int head_end = min(RESCALE_EVERY, maxlen);
-    if (head_end > 0) zip3_load_row<NT>(arow, C + (size_t)tok_at(0) * TOK, 0, lo, lx);
-    for (int t = 0; t < head_end; t += 2) two_steps(tok_at(t), tok_at(t + 1), tok_at(t + 2));
-    zip3_rescale<NT>(P, ex);
+    // A block of 16 positions in which not every lane's segment has a token (the first block: token 0 of a first
+    // segment went into the initial P, short segments; the blocks after the last full one: ragged ends, idle slots):
+    // one 16-byte load per lane - only where the segment still has tokens, so nothing is read past a stream's padded
+    // end - and the identity entry wherever there is no token; `npos` positions are stepped (even, <= 16).
+    auto masked_block = [&](int bi, int npos) __attribute__((always_inline)) {
+        uint4 ob = make_uint4(0u, 0u, 0u, 0u);
+        if (bi * RESCALE_EVERY < len) ob = *reinterpret_cast<const uint4 *>(tokp + (size_t)bi * RESCALE_EVERY);
+        const int live = len - bi * RESCALE_EVERY;              // positions u < live hold a token
+        const int dead0 = (first && bi == 0) ? 0 : -1;
+        const unsigned long long lo64 = (unsigned long long)ob.y << 32 | ob.x, hi64 = (unsigned long long)ob.w << 32 | ob.z;
+        auto tok_of = [&](int u) __attribute__((always_inline)) {
+            const unsigned long long h = u < 8 ? lo64 : hi64;
+            const int tk = (int)((h >> (8 * (u & 7))) & 0xffull);
+            return (u < live && u != dead0 && u < RESCALE_EVERY) ? tk : IDENT;
+        };
+        zip3_load_row<NT>(arow, C + (size_t)tok_of(0) * TOK, 0, lo, lx);
+        for (int u = 0; u < npos; u += 2) two_steps(tok_of(u), tok_of(u + 1), tok_of(u + 2));
+        zip3_rescale<NT>(P, ex);
+    };
+    if (maxlen > 0) masked_block(0, min(RESCALE_EVERY, (maxlen + 1) & ~1));
     for (int bi = 1; bi < nfull; ++bi) {
         const uint4 ob = *reinterpret_cast<const uint4 *>(tokp + (size_t)bi * RESCALE_EVERY);
         uint32_t w0 = ob.x, w1 = ob.y, w2 = ob.z, w3 = ob.w;
@@ -239,12 +252,8 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
         }
         zip3_rescale<NT>(P, ex);
     }
-    const int tail0 = max(RESCALE_EVERY, nfull * RESCALE_EVERY);
-    if (tail0 < maxlen) zip3_load_row<NT>(arow, C + (size_t)tok_at(tail0) * TOK, 0, lo, lx);
-    for (int t = tail0; t < maxlen; t += 2) {
-        two_steps(tok_at(t), tok_at(t + 1), tok_at(t + 2));
-        if (((t + 2) & (RESCALE_EVERY - 1)) == 0) zip3_rescale<NT>(P, ex);
-    }
+    for (int bi = max(1, nfull); bi * RESCALE_EVERY < maxlen; ++bi)
+        masked_block(bi, min(RESCALE_EVERY, (maxlen - bi * RESCALE_EVERY + 1) & ~1));
     zip3_rescale<NT>(P, ex);
 
     // ---- fold the workgroup's segments into one: P_0 <- P_{n-1} ... P_1 P_0 (binary tree through LDS) ----

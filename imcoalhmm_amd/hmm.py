@@ -142,6 +142,36 @@ class Forwarder(object):
         n = _capi.lib().imc_obs_compressed_length(self._h, int(alphabet_limit), ctypes.byref(used))
         return int(n), int(used.value)
 
+    # The attributes the reference's Forwarder keeps from ziphmm.preprocess_raw_observations (hmm.py:15-16).  Nothing
+    # outside hmm.py reads them; here they are views of the library's dictionary at its deepest level.
+    @property
+    def new_nsyms(self):
+        return self.compressed_length(1 << 30)[1]
+
+    @property
+    def sym2pair(self):
+        """{new symbol: (left, right)} for every merged token (the pair it replaces, in stream order)."""
+        L = _capi.lib()
+        used = ctypes.c_int(0)
+        _capi.check(L.imc_obs_dictionary(self._h, 1 << 30, None, None, 0, ctypes.byref(used)))
+        k = used.value - self.NSYM
+        left, right = np.zeros(max(k, 1), dtype=np.uint16), np.zeros(max(k, 1), dtype=np.uint16)
+        u16 = ctypes.POINTER(ctypes.c_uint16)
+        _capi.check(L.imc_obs_dictionary(self._h, 1 << 30, left.ctypes.data_as(u16), right.ctypes.data_as(u16), k,
+                                         ctypes.byref(used)))
+        return {self.NSYM + i: (int(left[i]), int(right[i])) for i in range(k)}
+
+    @property
+    def new_obs(self):
+        """The compressed observation sequence (int32 token ids), copied back from the device."""
+        L = _capi.lib()
+        n = ctypes.c_size_t(0)
+        _capi.check(L.imc_obs_tokens(self._h, 1 << 30, None, 0, ctypes.byref(n), None))
+        out = np.zeros(max(n.value, 1), dtype=np.uint16)
+        _capi.check(L.imc_obs_tokens(self._h, 1 << 30, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), n.value,
+                                     ctypes.byref(n), None))
+        return out[:n.value].astype(np.int32)
+
     @property
     def handle(self):
         return self._h

@@ -81,6 +81,15 @@ int imc_obs_nsym(const imc_obs *obs);
  * dictionary level whose alphabet is <= alphabet_limit; *alphabet_used gets that alphabet
  * (`new_nsyms`).  Returns the raw length when the chunk is not compressed. */
 size_t imc_obs_compressed_length(const imc_obs *obs, int alphabet_limit, int *alphabet_used);
+/* The other two results of ziphmm.preprocess_raw_observations (hmm.py:16), at the deepest dictionary level whose
+ * alphabet is <= alphabet_limit:  imc_obs_dictionary = `sym2pair` (token nsym + k is left[k] followed by right[k];
+ * call with left = right = NULL to get *alphabet_used first), imc_obs_tokens = `new_obs` (copied back from the
+ * device as 16-bit ids; call with tokens = NULL to get *length first).  Nothing in the reference reads them outside
+ * hmm.py; they exist for inspection and tests. */
+int imc_obs_dictionary(const imc_obs *obs, int alphabet_limit, uint16_t *left, uint16_t *right, size_t capacity,
+                       int *alphabet_used);
+int imc_obs_tokens(const imc_obs *obs, int alphabet_limit, uint16_t *tokens, size_t capacity, size_t *length,
+                   int *alphabet_used);
 int imc_obs_free(imc_obs *obs);
 
 /* Host-side ingestion helpers (no GPU needed) -------------------------------------------- */

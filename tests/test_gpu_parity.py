@@ -608,3 +608,30 @@ def test_quartet_alphabet_text_file_and_errors(tmp_path, oracle):
         Forwarder.from_array(np.zeros(4, dtype=np.uint8), 300)                        # bytes cannot carry 300 symbols
     with pytest.raises(ValueError):
         Forwarder.from_array(np.zeros(4, dtype=np.int32), 5000)                       # beyond the library's limit
+
+
+def test_forwarder_attributes_of_the_reference(example_pairs):
+    """hmm.py:15-16 keeps (new_obs, sym2pair, new_nsyms) on the Forwarder: expanding the compressed stream through
+    the pair table must give back the original observations, and position 0 is never merged."""
+    set_zip(1)
+    obs = np.tile(example_pairs["hg18__pantro2"], 2)
+    f = Forwarder.from_array(obs, 3)
+    assert f.NSYM == 3 and f.new_nsyms > 3
+    pairs, new_obs = f.sym2pair, f.new_obs
+    assert sorted(pairs) == list(range(3, f.new_nsyms)) and len(new_obs) == f.compressed_length(1 << 30)[0] < len(obs) // 8
+    assert new_obs[0] == obs[0]
+
+    def expand(z):
+        out, stack = [], [int(z)]
+        while stack:
+            t = stack.pop()
+            if t < 3:
+                out.append(t)
+            else:
+                stack.extend((pairs[t][1], pairs[t][0]))
+        return out
+    table = {z: expand(z) for z in range(f.new_nsyms)}
+    back = np.fromiter((s for z in new_obs for s in table[int(z)]), dtype=np.uint8)
+    assert np.array_equal(back, obs)
+    short = Forwarder.from_array(obs[:100], 3)                     # too short to compress: the raw stream itself
+    assert short.new_nsyms == 3 and short.sym2pair == {} and np.array_equal(short.new_obs, obs[:100])
