@@ -866,13 +866,25 @@ __global__ __launch_bounds__(256) void k_rank1_check(BigArgs a, const BigBlock *
     }
     if (tid == 0) s_bad = 0u;
     __syncthreads();
-    if (tid == 0) {   // reference column: the largest one (exponent first, then stored sum)
-        int best = 0;
-        for (int c = 1; c < N; ++c) {
-            const int eb = a.EX[gv + best], ec = a.EX[gv + c];
-            if (ec > eb || (ec == eb && s_sum[c] > s_sum[best])) best = c;
+    // reference column: the largest one (exponent first, then stored sum; ties: the lowest index) - an argmax over
+    // N <= 256 columns, one per thread, folded through LDS
+    {
+        __shared__ int s_idx[256], s_ex[256];
+        s_idx[tid] = tid < N ? tid : -1;
+        s_ex[tid] = tid < N ? a.EX[gv + tid] : 0;
+        __syncthreads();
+        for (int h = 128; h >= 1; h >>= 1) {
+            if (tid < h) {
+                const int ia = s_idx[tid], ib = s_idx[tid + h];
+                if (ib >= 0 && (ia < 0 || s_ex[tid + h] > s_ex[tid] || (s_ex[tid + h] == s_ex[tid] &&
+                                (s_sum[ib] > s_sum[ia] || (s_sum[ib] == s_sum[ia] && ib < ia))))) {
+                    s_idx[tid] = ib;
+                    s_ex[tid] = s_ex[tid + h];
+                }
+            }
+            __syncthreads();
         }
-        s_star = best;
+        if (tid == 0) s_star = s_idx[0];
     }
     __syncthreads();
     const int cs = s_star;
