@@ -4,6 +4,10 @@ one RCCL sum of the per-rank partial log-likelihoods (backend "nccl" is RCCL on 
 The path shards exactly where the reference's ``Likelihood.__call__`` sums over forwarders
 (src/IMCoalHMM/likelihood.py:33): chunks are independent, every rank holds the (tiny) parameter
 set, and the only exchange is ``all_reduce(sum)`` of B doubles per evaluation batch.
+
+Import order: ``import torch`` (and ``torch.cuda.set_device``) BEFORE the first call into libimcoal_fwd - the PyTorch
+wheel bundles its own HIP runtime, and whichever runtime initialises the GPU first is the only one that sees it
+(bench.py does exactly this; the other way round torch reports "No HIP GPUs are available").
 """
 import ctypes
 

@@ -134,3 +134,54 @@ def test_integration_md_stub_is_valid(tmp_path, oracle, hmm_params, example_pair
     got = f.forward(np.matrix(pi), np.matrix(T), np.matrix(E))      # the reference's model layer returns numpy.matrix
     want = oracle.forward_scaled(pi, T, E, obs)
     assert abs(got - want) / abs(want) < 1e-11
+
+
+DEVICE_PATH = textwrap.dedent('''
+    import ctypes, os, sys
+    import numpy as np
+    import torch                                   # torch first: its bundled HIP runtime must be the one that initialises
+    sys.path.insert(0, %r)
+    from imcoalhmm_amd import Forwarder, _capi, synth
+    from imcoalhmm_amd.hmm import forward_chunks_batch
+    from oracle import oracle_lib
+    oracle_lib.build()
+    d = np.load(os.path.join(%r, "tests", "golden", "hmm_params.npz"))
+    P = lambda k: (d[k + "_pi"], d[k + "_T"], d[k + "_E"])
+    torch.cuda.set_device(0)
+    chunks = [synth.sample_alignment(*P("iso20_t0"), n, seed=900 + k) for k, n in enumerate((70_000, 5_000, 33, 0, 120_000))]
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    handles = _capi.handle_array([f.handle for f in fw])
+    keys = ["iso20_t0", "iso20_t1", "iso20_t2", "iso20_t3", "im20_t0"]
+    sets = []
+    for a, b in zip(keys, keys[1:] + keys[:1]):          # B = 2 parameter sets per call
+        pa, pb = P(a), P(b)
+        sets.append(tuple(np.ascontiguousarray(np.stack([pa[k], pb[k]])) for k in range(3)))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    outs = [torch.full((2,), float("nan"), dtype=torch.float64, device=dev) for _ in sets]
+    L = _capi.lib()
+    for (pis, Ts, Es), out in zip(sets, outs):           # five calls back to back, no synchronisation in between
+        _capi.check(L.imc_forward_batch_device(handles, len(fw), 2, 20, 3, _capi.dptr(pis), _capi.dptr(Ts), _capi.dptr(Es),
+                                               ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
+    torch.cuda.synchronize()
+    for (pis, Ts, Es), out in zip(sets, outs):
+        want = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es)
+        got = out.cpu().numpy()
+        assert np.array_equal(got, want), (got, want)      # same plan, same kernels, same left-to-right chunk sum
+        for b in range(2):
+            ref = sum(oracle_lib.forward_scaled(pis[b], Ts[b], Es[b], c) for c in chunks)
+            assert abs(got[b] - ref) / abs(ref) < 1e-11
+    print("ok")
+''') % (REPO, REPO)
+
+
+def test_device_output_path_is_asynchronous_and_exact(tmp_path):
+    """imc_forward_batch_device (the multi-GPU building block, dist.py): partial sums stay on the device, the call
+    returns after enqueueing and stages its parameters through two pinned slots - five calls with different parameter
+    sets are issued back to back on torch's stream without any synchronisation, then every result must equal the
+    synchronous path's bit for bit.  (Own process: torch has to be imported before the library first touches HIP -
+    the wheel bundles its own HIP runtime - which is also the order bench.py and dist.py users follow.)"""
+    script = tmp_path / "device_path.py"
+    script.write_text(DEVICE_PATH)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-2000:])
