@@ -43,6 +43,7 @@
 #include "kernels_big.hpp"
 #include "kernels_zip2.hpp"
 #include "kernels_zip3.hpp"
+#include "kernels_zip4.hpp"
 #include "pair_dict.hpp"
 #include "obs_io.hpp"
 
@@ -109,8 +110,10 @@ struct Ctx {
     int kernel_pref = 0;      // 0 = automatic, 1 = vector kernels (k_propagate / k_zpropagate), 2 = blocked (k_zpropagate2)
     bool profile = false;
     bool rank1_handoff = true; // IMC_RANK1=0 switches the rank-one hand-off of the GEMM chain off (A/B measurements)
-    int blocked_variant = 3;  // register-blocked kernel: 3 = k_zpropagate3 (fp64 MFMA 4x4x4), 2 = k_zpropagate2 (DPP, VALU);
-                              // IMC_BLOCKED=2 pins the VALU variant (A/B measurements, tests)
+    int blocked_variant = 4;  // register-blocked kernel: 4 = fp64 MFMA 4x4x4 with the hybrid LDS/L2 table where it pays
+                              // (k_zpropagate4) and the LDS table otherwise (k_zpropagate3); 3 = LDS table only;
+                              // 5 = hybrid wherever it is possible (tests); 2 = k_zpropagate2 (DPP, VALU).
+                              // IMC_BLOCKED=2|3|4|5 at start-up
     bool guard = false;       // IMC_GUARD=1: every device buffer ends flush against an unmapped guard range (dev_alloc)
     bool use_graphs = false;  // IMC_GRAPH=1: replay each plan's launch sequence as a hipGraph (measured: no gain, the
                               // per-evaluation latency is kernel time + kernel boundaries, not host launch cost)
@@ -153,7 +156,7 @@ int ensure_ctx()
     HIP_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     g.use_graphs = std::getenv("IMC_GRAPH") != nullptr;
     if (const char *gd = std::getenv("IMC_GUARD")) g.guard = std::atoi(gd) != 0;
-    if (const char *bv = std::getenv("IMC_BLOCKED")) g.blocked_variant = std::atoi(bv) == 2 ? 2 : 3;
+    if (const char *bv = std::getenv("IMC_BLOCKED")) { const int v = std::atoi(bv); if (v >= 2 && v <= 5) g.blocked_variant = v; }
     if (const char *r1 = std::getenv("IMC_RANK1")) g.rank1_handoff = std::atoi(r1) != 0;
     g.pid = me;
     g.ready = true;
@@ -230,6 +233,7 @@ struct imc_obs {
     bool wide[imc::kNumLevels];            // ... holding 16-bit ids (alphabets beyond 256)
     size_t ntok[imc::kNumLevels];
     int alphabet[imc::kNumLevels];
+    std::vector<uint32_t> tok_count[imc::kNumLevels];   // byte levels: occurrences of every token id (hot-set choice of the hybrid table)
 };
 
 namespace {
@@ -349,8 +353,12 @@ int obs_upload(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym
             o->alphabet[l] = enc.alphabet[l];
             o->ntok[l] = enc.length[l];
             o->wide[l] = enc.is_wide[l];
-            if (l > 0 && enc.alphabet[l] == enc.alphabet[l - 1]) { o->d_tok[l] = o->d_tok[l - 1]; o->wide[l] = o->wide[l - 1]; continue; }
+            if (l > 0 && enc.alphabet[l] == enc.alphabet[l - 1]) { o->d_tok[l] = o->d_tok[l - 1]; o->wide[l] = o->wide[l - 1]; o->tok_count[l] = o->tok_count[l - 1]; continue; }
             if (enc.alphabet[l] <= nsym) { o->d_tok[l] = nullptr; continue; }   // raw stream: use d_sym
+            if (!enc.is_wide[l]) {
+                o->tok_count[l].assign((size_t)enc.alphabet[l], 0u);
+                for (size_t t = 1; t < enc.length[l]; ++t) o->tok_count[l][enc.bytes[l][t]]++;   // (position 0 is a raw symbol)
+            }
             hipError_t e3 = enc.is_wide[l]
                 ? upload_padded(reinterpret_cast<const uint8_t *>(enc.wide[l].data()), enc.length[l] * sizeof(imc::tok_t), &o->d_tok[l])
                 : upload_padded(enc.bytes[l].data(), enc.length[l], &o->d_tok[l]);
@@ -394,6 +402,12 @@ struct KernelChoice {
     void (*zip3)(BigArgs) = nullptr;   // ... its fp64-MFMA form (same launch geometry and block list)
     size_t (*zip3_lds)(int) = nullptr;
     bool zip3_attr_set = false;
+    void (*zip4)(BigArgs) = nullptr;   // ... with the hybrid LDS / L2 operator table, and the kernel that builds that table
+    void (*zip4_table)(BigArgs) = nullptr;
+    size_t (*zip4_lds)(int, int) = nullptr;
+    int (*zip4_max_hot)(int, size_t) = nullptr;
+    int tok_doubles = 0;               // doubles per table entry of the MFMA kernels
+    bool zip4_attr_set = false;
     // the blocked kernel in use (g.blocked_variant) and its LDS need for an alphabet of A tokens
     bool use3() const;
     size_t blocked_lds(int A) const { return use3() ? zip3_lds(A) : zip2_lds(A); }
@@ -410,6 +424,13 @@ KernelChoice make_kc()
         k.zip2_lds = &Zip2Geom<NP / 4>::lds_bytes;
         k.zip3 = k_zpropagate3<NP / 4>;
         k.zip3_lds = &Zip3Geom<NP / 4>::lds_bytes;
+        k.tok_doubles = Zip3Geom<NP / 4>::TOK;
+        if constexpr (NP <= 20) {   // (NP = 24: the extra 36 operand registers of the hybrid form would spill)
+            k.zip4 = k_zpropagate4<NP / 4>;
+            k.zip4_table = k_z4_table<NP / 4>;
+            k.zip4_lds = &Zip4Geom<NP / 4>::lds_bytes;
+            k.zip4_max_hot = &Zip4Geom<NP / 4>::max_hot;
+        }
     }
     return k;
 }
@@ -427,7 +448,7 @@ KernelChoice make_big()
                         BigSlab<NT, NSLAB>::bytes, nullptr, nullptr, false};
 }
 
-bool KernelChoice::use3() const { return zip3 && g.blocked_variant == 3; }
+bool KernelChoice::use3() const { return zip3 && g.blocked_variant >= 3; }
 
 KernelChoice kChoices[] = {
     make_kc<4, 1, 2>(), make_kc<4, 2, 2>(), make_kc<4, 3, 2>(), make_kc<4, 4, 2>(), make_kc<4, 5, 2>(),
@@ -454,8 +475,8 @@ KernelChoice *choose_kernel(int N, bool prefer_gemm)
 
 void reset_kernel_attributes()
 {
-    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.plain_attr_set = false;
-    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.plain_attr_set = false;
+    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.plain_attr_set = false;
+    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.plain_attr_set = false;
 }
 
 // ---- launch plan ----------------------------------------------------------------------------------
@@ -470,6 +491,10 @@ struct Group {             // one propagate launch
     BigBlock *d_big_blocks = nullptr;
     uint32_t *d_seg_ids = nullptr, *d_seg_out = nullptr;
     Z2Block *d_blocks = nullptr;
+    bool zip4 = false;                        // blocked MFMA kernel with the hybrid table: alphabet beyond LDS, n_hot operators cached
+    int n_hot = 0;
+    std::vector<uint16_t> hot;
+    uint16_t *d_hot = nullptr;
     uint16_t *d_tab_order = nullptr;          // blocked MFMA kernel: merged tokens of the alphabet by dictionary depth
     int *d_tab_lvl = nullptr;
     int tab_nlvl = 0;
@@ -541,7 +566,7 @@ struct Plan {
         if (graph) (void)hipGraphExecDestroy(graph);
         dev_free(d_segs); dev_free(d_vecs); dev_free(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
+        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
         dev_free(d_params); dev_free(d_out);
         for (int k = 0; k < 2; ++k) { (void)hipHostFree(h_params[k]); if (ev_params[k]) (void)hipEventDestroy(ev_params[k]); }
         (void)hipHostFree(h_out);
@@ -666,6 +691,7 @@ struct PlanBuilder {
         // the operator table per evaluation ((A - S) dependent small products), which dominates on short inputs.
         // Estimate: table build + main loop with all 16-lane rows of the machine busy.
         std::map<const DictDev *, int> dict_level;
+        const bool mfma_blocked = !big && kc->use3() && g.kernel_pref != 1;
         if (g.compression) {
             std::map<const DictDev *, std::vector<int>> by_dict;
             for (int f = 0; f < n_chunks; ++f)
@@ -675,6 +701,44 @@ struct PlanBuilder {
                 int best_l = -1;
                 for (int l = 0; l < imc::kNumLevels; ++l) {
                     const imc_obs *o0 = chunks[kv.second[0]];
+                    if (mfma_blocked) {
+                        // Blocked MFMA kernels, estimated in microseconds: the table is built one dictionary depth at
+                        // a time (32 tokens per pass), the scan advances cus * 32 segments per wavefront-step.  Levels
+                        // that fit LDS run k_zpropagate3; byte levels beyond that can run k_zpropagate4 (hybrid table:
+                        // one workgroup builds it in L2, steps on tokens outside the LDS-cached hot set cost ~12 % more).
+                        const int A = o0->alphabet[l];
+                        if (!(A > o0->nsym && A <= imc::kByteAlphabet && o0->d_tok[l]) || o0->wide[l]) continue;
+                        const bool fits = kc->blocked_lds(A) <= LDS_BUDGET;
+                        const int max_hot = kc->zip4 ? kc->zip4_max_hot(A, LDS_BUDGET) : 0;
+                        const bool hybrid_ok = !fits && kc->zip4 && g.blocked_variant >= 4 && max_hot >= 8 && !o0->tok_count[l].empty();
+                        if (!fits && !hybrid_ok) continue;
+                        double toks = 0.0;
+                        for (int f : kv.second) toks += (double)chunks[f]->ntok[l];
+                        int passes = 0;
+                        {
+                            std::map<int, int> per_depth;
+                            for (int z = o0->nsym; z < A; ++z) per_depth[kv.first->depth[z]]++;
+                            for (auto &pd : per_depth) passes += (pd.second + (int)Z2SLOTS - 1) / (int)Z2SLOTS;
+                        }
+                        const double nt = kc->NP / 4.0, t_step = std::max(0.25, 1.88 * nt * nt * nt / 125.0);
+                        const double steps = std::max(16.0, toks * B / ((double)g.cus * Z2SLOTS));
+                        double cost;
+                        if (fits) cost = passes * 1.1 + steps * t_step;
+                        else {
+                            std::vector<uint64_t> cnt((size_t)A, 0);
+                            for (int f : kv.second)
+                                for (size_t z = 0; z < chunks[f]->tok_count[l].size() && z < cnt.size(); ++z) cnt[z] += chunks[f]->tok_count[l][z];
+                            std::vector<uint64_t> sorted(cnt);
+                            std::sort(sorted.begin(), sorted.end(), std::greater<uint64_t>());
+                            uint64_t all = 0, top = 0;
+                            for (size_t z = 0; z < sorted.size(); ++z) { all += sorted[z]; if ((int)z < std::min(max_hot, A)) top += sorted[z]; }
+                            const double cold = all ? 1.0 - (double)top / (double)all : 0.0;
+                            cost = passes * 2.3 + 7.0 + steps * t_step * (1.0 + 0.12 * cold);
+                        }
+                        if (g.blocked_variant == 5 && !fits) cost *= 1e-3;      // tests: the hybrid table wherever it is possible
+                        if (cost < best) { best = cost; best_l = l; }
+                        continue;
+                    }
                     if (!(o0->alphabet[l] <= a_max && o0->alphabet[l] > o0->nsym && o0->d_tok[l])) continue;
                     if (big && (size_t)B * o0->alphabet[l] * kc->NP * kc->NP * 8 > CTAB_BUDGET) continue;   // table too large
                     double toks = 0.0;
@@ -699,7 +763,9 @@ struct PlanBuilder {
                 if (const char *fl = std::getenv("IMC_FORCE_LEVEL")) {   // experiments only: pin the dictionary level index
                     const int l = std::atoi(fl);
                     const imc_obs *o0 = chunks[kv.second[0]];
-                    if (l >= 0 && l < imc::kNumLevels && o0->alphabet[l] <= a_max && o0->alphabet[l] > o0->nsym && o0->d_tok[l]) best_l = l;
+                    const int amax_forced = mfma_blocked && kc->zip4 && g.blocked_variant >= 4 ? imc::kByteAlphabet : a_max;
+                    if (l >= 0 && l < imc::kNumLevels && o0->alphabet[l] <= amax_forced && o0->alphabet[l] > o0->nsym && o0->d_tok[l] &&
+                        !(mfma_blocked && o0->wide[l])) best_l = l;
                 }
                 dict_level[kv.first] = best_l;
             }
@@ -724,6 +790,8 @@ struct PlanBuilder {
                 gr.big = big;
                 gr.A = S;
                 if (gr.zip) { gr.dict = o->dict; gr.A = o->alphabet[level]; }
+                // an alphabet beyond LDS can only have been chosen for the hybrid-table kernel
+                gr.zip4 = gr.zip && mfma_blocked && kc->blocked_lds(gr.A) > LDS_BUDGET;
                 p->groups.push_back(gr);
                 gi = (int)p->groups.size() - 1;
             }
@@ -783,7 +851,7 @@ struct PlanBuilder {
                 gr.seglen = seg_vec;
                 // ... or the register-blocked kernel (one operator per 16-lane row): fill every row of the machine
                 // once; first segments waste 1 - 1/N of their row, which the cost comparison accounts for
-                if (kc->zip2 && g.kernel_pref != 1 && kc->blocked_lds(gr.A) <= LDS_BUDGET && (gr.zip || (S == gr.A && S <= imc::kByteAlphabet))) {
+                if (kc->zip2 && g.kernel_pref != 1 && (kc->blocked_lds(gr.A) <= LDS_BUDGET || gr.zip4) && (gr.zip || (S == gr.A && S <= imc::kByteAlphabet))) {
                     size_t total = 0;
                     for (size_t L : lens) total += L;
                     const double rows = (double)g.cus * Z2WAVES * 4;
@@ -807,8 +875,11 @@ struct PlanBuilder {
                         for (int it = 0; it < 1024 && rows_used(sg) > target; ++it) sg += Z2GRAN;
                         const double used = rows_used(sg);
                         // per round of workgroups: the main loop, plus the table rebuild and the 5-level in-kernel fold
-                        const double fixed = (double)(gr.A - S) * (400.0 + (double)kc->NP * kc->NP * kc->NP / 64.0)
-                                             + 5.0 * (Z2WAVES / 4.0) * step_cycles;
+                        // (table: the VALU form builds token by token; the MFMA form one dictionary depth per pass,
+                        // ~10 depths; with the hybrid table a workgroup only copies its hot set from L2)
+                        const double table = !kc->use3() ? (double)(gr.A - S) * (400.0 + (double)kc->NP * kc->NP * kc->NP / 64.0)
+                                             : gr.zip4 ? 9000.0 : 2600.0 * std::min(12.0, (double)(gr.A - S));
+                        const double fixed = table + 5.0 * (Z2WAVES / 4.0) * step_cycles;
                         const double c = std::ceil(used * B / rows) * ((double)sg * (Z2WAVES / 4.0) * step_cycles + fixed);
                         if (c < cost_blk) { cost_blk = c; seg_blk = sg; slots = used; }
                     }
@@ -816,7 +887,7 @@ struct PlanBuilder {
                         std::fprintf(stderr, "[imc] plan: vector kernel seg %zu cost %.3g cycles; blocked kernel seg %zu slots %.0f cost %.3g cycles\n",
                                      seg_vec, cost_vec, seg_blk, slots, cost_blk);
                     const bool vec_fits = !gr.zip || kc->zip_lds(gr.A) <= LDS_BUDGET;   // the table may only fit the blocked kernel
-                    if (g.kernel_pref == 2 || cost_blk < cost_vec || !vec_fits) { gr.zip2 = true; gr.seglen = seg_blk; }
+                    if (g.kernel_pref == 2 || cost_blk < cost_vec || !vec_fits || gr.zip4) { gr.zip2 = true; gr.seglen = seg_blk; }
                 }
             }
             if (g.seg_override) gr.seglen = round_up(std::max<size_t>(g.seg_override, 16), 16);   // tests: force stitching
@@ -1008,6 +1079,20 @@ struct PlanBuilder {
         }
         for (Group &gr : q->groups) {
             if (gr.zip2 && e == hipSuccess) e = up((void **)&gr.d_blocks, gr.blocks.data(), gr.blocks.size() * sizeof(Z2Block));
+            if (gr.zip4 && e == hipSuccess) {
+                // hot set: the most frequent tokens of this group's chunks, as many as LDS holds beside the identity
+                std::vector<uint64_t> cnt((size_t)gr.A, 0);
+                for (int f : gr.chunks)
+                    for (size_t z = 0; z < chunks[f]->tok_count[gr.level].size() && z < cnt.size(); ++z) cnt[z] += chunks[f]->tok_count[gr.level][z];
+                std::vector<uint16_t> ids((size_t)gr.A);
+                for (int z = 0; z < gr.A; ++z) ids[z] = (uint16_t)z;
+                std::stable_sort(ids.begin(), ids.end(), [&](uint16_t x, uint16_t y) { return cnt[x] > cnt[y]; });
+                gr.n_hot = std::min(gr.A, kc->zip4_max_hot(gr.A, LDS_BUDGET));
+                gr.hot.assign(ids.begin(), ids.begin() + gr.n_hot);
+                e = up((void **)&gr.d_hot, gr.hot.data(), gr.hot.size() * sizeof(uint16_t));
+                if (e == hipSuccess) e = dev_alloc((void **)&gr.d_Ctab, (size_t)B * (gr.A + 1) * kc->tok_doubles * 8);
+                if (e == hipSuccess) e = dev_alloc((void **)&gr.d_cex, (size_t)B * (gr.A + 1) * 4 + 16);
+            }
             if (gr.zip2 && gr.zip && e == hipSuccess) {
                 // merged tokens of this level's alphabet (ids S .. A-1) grouped by dictionary depth, for the table build
                 const DictDev &dd = *gr.dict;
@@ -1230,7 +1315,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.phase = gr.rank1 ? 1 : 0; ba.t_from = 0; ba.t_to = gr.rank1 ? gr.checkpoints[0] : INT_MAX;
             ba.r1flag = gr.d_r1flag; ba.r1at = gr.d_r1at; ba.r1u = gr.d_r1u;
             ba.r1alpha = gr.d_r1alpha; ba.n_segs = p->n_segs;
-            ba.tab_order = nullptr; ba.tab_lvl = nullptr; ba.tab_nlvl = 0;
+            ba.tab_order = nullptr; ba.tab_lvl = nullptr; ba.tab_nlvl = 0; ba.hot = nullptr; ba.n_hot = 0;
             if (gr.rank1) HIP_TRY(hipMemsetAsync(gr.d_r1flag, 0, (size_t)B * p->n_segs * 4, stream));   // nothing certified yet
             hipLaunchKernelGGL(kc->big_table_raw, dim3((unsigned)S, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
@@ -1311,6 +1396,24 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.Ctab = nullptr; ba.cex = nullptr;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
             ba.tab_order = gr.d_tab_order; ba.tab_lvl = gr.d_tab_lvl; ba.tab_nlvl = gr.tab_nlvl;
+            ba.hot = gr.d_hot; ba.n_hot = gr.n_hot;
+            if (gr.zip4) {
+                // hybrid table: one workgroup per parameter set builds the operators in global memory (they stay in
+                // L2), then the scan caches the hot ones in LDS and streams the rest a step ahead
+                ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex;
+                hipLaunchKernelGGL(kc->zip4_table, dim3(1, (unsigned)B), dim3(Z2WAVES * 64), (size_t)(5 * gr.A + 16) * 4, stream, ba);
+                HIP_TRY(hipGetLastError());
+                if (!kc->zip4_attr_set) {
+                    HIP_TRY(hipFuncSetAttribute((const void *)kc->zip4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+                    kc->zip4_attr_set = true;
+                }
+                hipLaunchKernelGGL(kc->zip4, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64),
+                                   kc->zip4_lds(gr.A, gr.n_hot), stream, ba);
+                note(std::string("k_zpropagate4<") + std::to_string(NP / 4) + ">" + strm);
+                lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A);
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
             const bool v3 = kc->use3();
             bool &attr_set = v3 ? kc->zip3_attr_set : kc->zip2_attr_set;
             if (!attr_set) {
@@ -1781,7 +1884,7 @@ int imc_set_rank1_handoff(int on)
 int imc_set_blocked_kernel(int variant)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    if (variant != 2 && variant != 3) return fail(IMC_ERR_ARG, "blocked kernel variant must be 2 (VALU/DPP) or 3 (fp64 MFMA)");
+    if (variant < 2 || variant > 5) return fail(IMC_ERR_ARG, "blocked kernel variant must be 2 (VALU/DPP), 3 (fp64 MFMA, LDS table), 4 (+ hybrid table, default) or 5 (hybrid wherever possible)");
     g.blocked_variant = variant;            // (part of the plan key: cached plans of the other variant stay valid)
     return IMC_OK;
 }

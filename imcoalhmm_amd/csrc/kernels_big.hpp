@@ -55,6 +55,9 @@ struct BigArgs {
     const uint16_t *tab_order;
     const int *tab_lvl;
     int tab_nlvl;
+    // k_zpropagate4 (hybrid table): the n_hot most frequent tokens of the launch's chunks, cached in LDS (slot k = hot[k])
+    const uint16_t *hot;
+    int n_hot;
 };
 
 

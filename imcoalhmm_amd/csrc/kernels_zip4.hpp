@@ -1,0 +1,373 @@
+// kernels_zip4.hpp - the register-blocked MFMA kernel (kernels_zip3.hpp) with a HYBRID operator table: a dictionary far
+// larger than LDS can hold (up to 256 tokens at N = 20, ~100 alignment columns per token instead of ~61 with the 44
+// that fit), its operators in a global table that stays in L2 (256 x 3.2 KB = 0.8 MB), the most frequent ones also
+// cached in LDS.  Included by imcoal_fwd.hip only.
+//
+//   * k_z4_table<NT>: one workgroup per parameter set builds the table in global memory, one dictionary depth at a
+//     time with the MFMA step itself (four tokens per wavefront, as in k_zpropagate3's prologue; operands gathered
+//     from the table's lower depths in L2).
+//   * k_zpropagate4<NT>: k_zpropagate3's scan.  Every workgroup copies the H hottest operators (+ the identity) from
+//     the global table into LDS.  A step whose token is hot reads its A operands from LDS one tile-row ahead, exactly
+//     as k_zpropagate3; a step whose token is cold takes them from 25 registers per lane that were loaded from the
+//     global table ONE STEP (NT^3 MFMAs, ~1 us) ahead - tile-row I of the next cold operator is requested right after
+//     tile-row I of the current one has been consumed, so a single register set suffices and an L2 hit is never
+//     waited for.  Measured feasibility (scratch microbenchmark, 3.3 MB table, 85 % of the steps cold): +10 % per step.
+#pragma once
+#include "kernels_zip3.hpp"
+
+template <int NT>
+struct Zip4Geom {
+    using G3 = Zip3Geom<NT>;
+    static constexpr int TOK = G3::TOK;
+    // LDS: `slots` operator entries (hot operators + identity; later the fold's exchange area), the slot map and the
+    // exponents of all A + 1 table entries
+    static constexpr int slots(int H) { return (H + 1 > Z2SLOTS + 1 ? H + 1 : Z2SLOTS + 1); }
+    static constexpr size_t lds_bytes(int A, int H) { return (size_t)slots(H) * TOK * 8 + (size_t)(2 * (A + 2) + 64) * 4 + 16; }
+    // how many hot operators fit beside the identity
+    static constexpr int max_hot(int A, size_t budget)
+    {
+        const size_t fixed = (size_t)(2 * (A + 2) + 64) * 4 + 16;
+        const size_t n = budget > fixed ? (budget - fixed) / ((size_t)TOK * 8) : 0;
+        return n > 1 ? (int)n - 1 : 0;
+    }
+};
+
+// Pout <- C * Pin with the A operands of all tile-rows in registers (Areg[I][K] = this lane's C[4I + r][4K + q]).
+template <int NT>
+__device__ __forceinline__ void zip4_step_regs(const double (&Pin)[NT][NT], double (&Pout)[NT][NT], const double (&Areg)[NT][NT])
+{
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+                Pout[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(Areg[I][K], Pin[K][J], K == 0 ? 0.0 : Pout[I][J], 0, 0, 0);
+}
+
+// this lane's A operands of tile-row I of the table entry at Gz (global memory, the LDS entries' own layout)
+template <int NT>
+__device__ __forceinline__ void zip4_load_row_global(double (&a)[NT], const double *Gz, int I, int lo, int lx)
+{
+    using Geo = Zip3Geom<NT>;
+    const double2 *m = reinterpret_cast<const double2 *>(Gz + I * 16 * Geo::NTE + lo);
+#pragma unroll
+    for (int k2 = 0; k2 < Geo::NTE / 2; ++k2) {
+        const double2 v = m[k2];
+        a[2 * k2] = v.x;
+        a[2 * k2 + 1] = v.y;
+    }
+    if constexpr (NT & 1) a[NT - 1] = Gz[Geo::MAIN + I * 16 + lx];
+}
+
+// ---- the global table ---------------------------------------------------------------------------------------------
+// a.Ctab: [B][A + 1][TOK] (entry A = identity), a.cex: [B][A + 1].  One workgroup per parameter set.
+template <int NT>
+__global__ __launch_bounds__(Z2WAVES * 64) void k_z4_table(BigArgs a)
+{
+    using Geo = Zip3Geom<NT>;
+    constexpr int NP = Geo::NP, TOK = Geo::TOK, THREADS = Z2WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) int lds_i[];
+    int *m_cex = lds_i;                         // [A + 1]
+    int *m_left = m_cex + a.A + 1, *m_right = m_left + a.A, *m_order = m_right + a.A, *m_lvl = m_order + a.A;   // [A] x3, [A + 2]
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const double *pp = a.params + (size_t)b * a.pstride;
+    const double *Tp = pp + a.PP;
+    const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
+    double *Gt = a.Ctab + (size_t)b * (a.A + 1) * TOK;
+    const int IDENT = a.A;
+    for (int idx = tid; idx < (a.S + 1) * NP * NP; idx += THREADS) {
+        const int sidx = idx / (NP * NP);
+        const int rem = idx - sidx * NP * NP;
+        const int i = rem / NP, j = rem - i * NP;
+        if (sidx < a.S) Gt[(size_t)sidx * TOK + Geo::idx(i, j)] = Etg[(size_t)sidx * a.PP + i] * Tp[(size_t)j * a.PP + i];
+        else Gt[(size_t)IDENT * TOK + Geo::idx(i, j)] = i == j ? 1.0 : 0.0;
+    }
+    if (tid < a.S) m_cex[tid] = 0;
+    if (tid == 0) m_cex[IDENT] = 0;
+    for (int z = a.S + tid; z < a.A; z += THREADS) { m_left[z] = a.tok_left[z]; m_right[z] = a.tok_right[z]; }
+    for (int k = tid; k < a.A - a.S && a.tab_nlvl > 0; k += THREADS) m_order[k] = a.tab_order[k];
+    for (int k = tid; k <= a.tab_nlvl && a.tab_nlvl > 0; k += THREADS) m_lvl[k] = a.tab_lvl[k];
+    __threadfence_block();
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    const int q = lane >> 4, bq = (lane >> 2) & 3, r = lane & 3;
+    const int lo = (q * 4 + r) * Geo::NTE, lx = q * 4 + r;
+    for (int d = 0; d < a.tab_nlvl; ++d) {
+        const int o0 = m_lvl[d], o1 = m_lvl[d + 1];
+        for (int base = o0; base < o1; base += Z2SLOTS) {
+            if (base + wv * 4 >= o1) continue;               // nothing for this wavefront (wavefront-uniform)
+            const int ti = base + wv * 4 + bq;
+            const bool have = ti < o1;
+            const int z = have ? m_order[ti] : IDENT;
+            const int zl = have ? m_left[z] : IDENT, zr = have ? m_right[z] : IDENT;
+            const double *Gl = Gt + (size_t)zl * TOK, *Gr = Gt + (size_t)zr * TOK;
+            double Bt[NT][NT], Ar[NT][NT], Out[NT][NT];
+#pragma unroll
+            for (int K = 0; K < NT; ++K)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) Bt[K][J] = Gl[Geo::idx(4 * K + q, 4 * J + r)];
+#pragma unroll
+            for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(Ar[I], Gr, I, lo, lx);
+            zip4_step_regs<NT>(Bt, Out, Ar);
+            int e2 = 0;
+            zip3_rescale<NT>(Out, e2);
+            if (have) {
+                double *Gz = Gt + (size_t)z * TOK;
+#pragma unroll
+                for (int K = 0; K < NT; ++K)
+#pragma unroll
+                    for (int J = 0; J < NT; ++J) Gz[Geo::idx(4 * K + q, 4 * J + r)] = Out[K][J];
+                if (q == 0 && r == 0) m_cex[z] = m_cex[zl] + m_cex[zr] + e2;
+            }
+        }
+        // the next depth's wavefronts (same workgroup, same CU) read what this depth stored: stores are complete at the
+        // barrier, and no line of these entries can have been cached before it was written (each entry - a whole number
+        // of 128-byte lines - is written once per launch, before its first read)
+        __threadfence_block();
+        __syncthreads();
+    }
+    int *Gc = a.cex + (size_t)b * (a.A + 1);
+    for (int z = tid; z <= a.A; z += THREADS) Gc[z] = m_cex[z];
+}
+
+// ---- the scan -----------------------------------------------------------------------------------------------------
+struct Z4Tok {              // one step's operator for this lane's segment
+    int s;                  // LDS slot (0 when cold: a valid address whose data is not used)
+    int ce;                 // its power-of-two exponent
+    bool cold;              // not cached in LDS: operands come from the registers loaded from the global table
+    const double *g;        // its global table entry
+};
+
+// Pout <- C_cur * Pin.  `al` holds tile-row 0 of cur's LDS entry on entry and of nxt's on exit (as zip3_step);
+// `pre` holds ALL tile-rows of cur's global entry if cur is cold, and is refilled tile-row by tile-row with nxt's
+// entry (if that is cold) as soon as each row has been consumed.
+template <int NT>
+__device__ __forceinline__ void zip4_step(const double (&Pin)[NT][NT], double (&Pout)[NT][NT], const double *C, const Z4Tok &cur,
+                                          const Z4Tok &nxt, double (&al)[NT], double (&pre)[NT][NT], int lo, int lx)
+{
+    constexpr int TOK = Zip3Geom<NT>::TOK;
+    const double *Cz = C + (size_t)cur.s * TOK, *Cn = C + (size_t)nxt.s * TOK;
+#pragma unroll
+    for (int I = 0; I < NT; ++I) {
+        double an[NT], av[NT];
+        if (I + 1 < NT) zip3_load_row<NT>(an, Cz, I + 1, lo, lx);
+        else zip3_load_row<NT>(an, Cn, 0, lo, lx);
+#pragma unroll
+        for (int K = 0; K < NT; ++K) av[K] = cur.cold ? pre[I][K] : al[K];
+        __builtin_amdgcn_sched_barrier(0);         // keep the LDS prefetch ahead of this tile-row's MFMAs
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J)
+                Pout[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[K], Pin[K][J], K == 0 ? 0.0 : Pout[I][J], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt.cold) zip4_load_row_global<NT>(pre[I], nxt.g, I, lo, lx);   // (per lane; a full step ahead of its use)
+#pragma unroll
+        for (int K = 0; K < NT; ++K) al[K] = an[K];
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigArgs a)
+{
+    using Geo = Zip3Geom<NT>;
+    using G4 = Zip4Geom<NT>;
+    constexpr int NP = Geo::NP, TOK = Geo::TOK, THREADS = Z2WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int H = a.n_hot;                                             // hot operators; LDS slot H = the identity
+    double *C = lds;                                                   // [slots(H)][TOK]
+    int *cex = reinterpret_cast<int *>(C + (size_t)G4::slots(H) * TOK);   // [A + 1] exponents of the table entries
+    int *slot_of = cex + a.A + 2;                                      // [A + 1] LDS slot of a token, -1 = cold
+    int *xex = slot_of + a.A + 2;                                      // [Z2SLOTS + 1] the fold's exchange exponents
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const double *pp = a.params + (size_t)b * a.pstride;
+    const double *pi_p = pp;
+    const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
+    const double *Gt = a.Ctab + (size_t)b * (a.A + 1) * TOK;
+    const int *Gc = a.cex + (size_t)b * (a.A + 1);
+    const int IDENT = a.A;
+
+    // ---- LDS: exponents, slot map, the hot operators and the identity ----
+    for (int z = tid; z <= a.A; z += THREADS) { cex[z] = Gc[z]; slot_of[z] = -1; }
+    __syncthreads();
+    for (int k = tid; k <= H; k += THREADS) slot_of[k < H ? (int)a.hot[k] : IDENT] = k;
+    for (int idx = tid; idx < (H + 1) * (TOK / 2); idx += THREADS) {
+        const int k = idx / (TOK / 2), w = idx - k * (TOK / 2);
+        const int z = k < H ? (int)a.hot[k] : IDENT;
+        reinterpret_cast<double2 *>(C + (size_t)k * TOK)[w] = reinterpret_cast<const double2 *>(Gt + (size_t)z * TOK)[w];
+    }
+    __syncthreads();
+
+    // ---- scan: one segment per MFMA block ----
+    const int lane = tid & 63;
+    const int q = lane >> 4, bq = (lane >> 2) & 3, r = lane & 3;
+    const int lo = (q * 4 + r) * Geo::NTE, lx = q * 4 + r;
+    const Z2Block blk = a.blocks[blockIdx.x];
+    const int slot = (tid >> 6) * 4 + bq;                   // 0..Z2SLOTS-1 within the workgroup
+    const bool valid = slot < (int)blk.n;
+    const uint32_t seg = blk.seg0 + (valid ? slot : 0);
+    const SegDesc sd = a.segs[seg];
+    const int len = valid ? (int)sd.len : 0;
+    const bool first = (sd.first & SEG_FIRST) != 0;
+    const uint8_t *tokp = sd.obs;
+
+    double P[NT][NT], Q[NT][NT];
+    {
+        const int tok0 = (valid && first) ? (int)tokp[0] : 0;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                const int i = 4 * K + q, c = 4 * J + r;
+                double v;
+                if (first) v = (c == 0 && i < a.N) ? pi_p[i] * Etg[(size_t)tok0 * a.PP + i] : 0.0;
+                else v = (i == c && i < a.N) ? 1.0 : 0.0;
+                P[K][J] = valid ? v : 0.0;
+            }
+    }
+    int ex = 0;
+    const int maxlen = wave_max_i32(len);
+    const int nfull = maxlen == 0 ? 0 : wave_min_i32(valid ? len / RESCALE_EVERY : INT_MAX);   // idle wavefronts still join the fold's barriers
+
+    double al[NT], pre[NT][NT];
+#pragma unroll
+    for (int I = 0; I < NT; ++I)
+#pragma unroll
+        for (int K = 0; K < NT; ++K) pre[I][K] = 0.0;
+    auto mk = [&](int tok) __attribute__((always_inline)) {
+        Z4Tok t;
+        const int s = slot_of[tok];
+        t.cold = s < 0;
+        t.s = t.cold ? 0 : s;
+        t.ce = cex[tok];
+        t.g = Gt + (size_t)tok * TOK;
+        return t;
+    };
+    // start (or restart) the pipeline at `c`: its LDS row 0 and, if it is cold, all of its global rows - exposed latency,
+    // paid at the start of a segment and where the token of the next position is not known a step ahead
+    auto prime = [&](const Z4Tok &c) __attribute__((always_inline)) {
+        zip3_load_row<NT>(al, C + (size_t)c.s * TOK, 0, lo, lx);
+        if (c.cold) {
+#pragma unroll
+            for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(pre[I], c.g, I, lo, lx);
+        }
+    };
+    auto two_steps = [&](const Z4Tok &t0, const Z4Tok &t1, const Z4Tok &tn) __attribute__((always_inline)) {
+        zip4_step<NT>(P, Q, C, t0, t1, al, pre, lo, lx);
+        zip4_step<NT>(Q, P, C, t1, tn, al, pre, lo, lx);
+        ex += t0.ce + t1.ce;
+    };
+    // A block of 16 positions in which not every lane's segment has a token (see k_zpropagate3): one 16-byte load per
+    // lane where the segment still has tokens, the identity elsewhere; the pipeline is primed at its first position.
+    auto masked_block = [&](int bi, int npos) __attribute__((always_inline)) {
+        uint4 ob = make_uint4(0u, 0u, 0u, 0u);
+        if (bi * RESCALE_EVERY < len) ob = *reinterpret_cast<const uint4 *>(tokp + (size_t)bi * RESCALE_EVERY);
+        const int live = len - bi * RESCALE_EVERY;
+        const int dead0 = (first && bi == 0) ? 0 : -1;
+        const unsigned long long lo64 = (unsigned long long)ob.y << 32 | ob.x, hi64 = (unsigned long long)ob.w << 32 | ob.z;
+        auto tok_of = [&](int u) __attribute__((always_inline)) {
+            const unsigned long long h = u < 8 ? lo64 : hi64;
+            const int tk = (int)((h >> (8 * (u & 7))) & 0xffull);
+            return (u < live && u != dead0 && u < RESCALE_EVERY) ? tk : IDENT;
+        };
+        Z4Tok c0 = mk(tok_of(0));
+        prime(c0);
+        for (int u = 0; u < npos; u += 2) {
+            const Z4Tok c1 = mk(tok_of(u + 1)), c2 = mk(tok_of(u + 2));
+            two_steps(c0, c1, c2);
+            c0 = c2;
+        }
+        zip3_rescale<NT>(P, ex);
+    };
+    if (maxlen > 0) masked_block(0, min(RESCALE_EVERY, (maxlen + 1) & ~1));
+    if (nfull > 1) {
+        // full blocks: the 16 bytes of block bi + 1 are fetched while block bi runs, so the first token of the next
+        // block is known a step ahead and the cold-operand pipeline never drains inside this loop
+        uint4 ob = *reinterpret_cast<const uint4 *>(tokp + RESCALE_EVERY);
+        Z4Tok c0 = mk((int)(ob.x & 0xffu));
+        prime(c0);
+        for (int bi = 1; bi < nfull; ++bi) {
+            uint4 nb = ob;
+            if (bi + 1 < nfull) nb = *reinterpret_cast<const uint4 *>(tokp + (size_t)(bi + 1) * RESCALE_EVERY);
+            uint32_t w0 = ob.x, w1 = ob.y, w2 = ob.z, w3 = ob.w;
+#pragma unroll 1
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const uint32_t w = w0;
+                w0 = w1; w1 = w2; w2 = w3; w3 = nb.x;
+                const Z4Tok c1 = mk((int)((w >> 8) & 0xffu)), c2 = mk((int)((w >> 16) & 0xffu));
+                two_steps(c0, c1, c2);
+                // (behind the last full block the pipeline is pointed at the identity: the block that follows, if any,
+                // is a masked one and primes itself)
+                const Z4Tok c3 = mk((int)(w >> 24)), c4 = mk((g4 == 3 && bi + 1 >= nfull) ? IDENT : (int)(w0 & 0xffu));
+                two_steps(c2, c3, c4);
+                c0 = c4;
+            }
+            zip3_rescale<NT>(P, ex);
+            ob = nb;
+        }
+    }
+    for (int bi = max(1, nfull); bi * RESCALE_EVERY < maxlen; ++bi)
+        masked_block(bi, min(RESCALE_EVERY, (maxlen - bi * RESCALE_EVERY + 1) & ~1));
+    zip3_rescale<NT>(P, ex);
+
+    // ---- fold the workgroup's segments into one (k_zpropagate3's fold: LDS entries become the exchange area) ----
+    for (int stride = 1; stride < Z2SLOTS; stride <<= 1) {
+        if ((int)blk.n <= stride) break;          // workgroup-uniform
+        __syncthreads();                          // table (or previous level's exchange data) no longer read
+        if (stride == 1) {
+            for (int idx = tid; idx < NP * NP; idx += THREADS) {
+                const int i = idx / NP, j = idx - i * NP;
+                C[(size_t)Z2SLOTS * TOK + Geo::idx(i, j)] = i == j ? 1.0 : 0.0;
+            }
+            if (tid == 0) xex[Z2SLOTS] = 0;
+        }
+        if (valid && (slot & stride) && !(slot & (stride - 1))) {   // this slot is a partner ("hi") at this level
+            double *dst = C + (size_t)slot * TOK;
+#pragma unroll
+            for (int K = 0; K < NT; ++K)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) dst[Geo::idx(4 * K + q, 4 * J + r)] = P[K][J];
+            if (q == 0 && r == 0) xex[slot] = ex;
+        }
+        __syncthreads();
+        const bool act = valid && !(slot & (2 * stride - 1)) && slot + stride < (int)blk.n;
+        const int src = act ? slot + stride : Z2SLOTS;
+        zip3_load_row<NT>(al, C + (size_t)src * TOK, 0, lo, lx);
+        zip3_step<NT>(P, Q, C + (size_t)src * TOK, C + (size_t)src * TOK, al, lo, lx);
+        ex += xex[src];
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) P[K][J] = Q[K][J];
+        zip3_rescale<NT>(P, ex);
+    }
+
+    if (slot == 0) {
+        const size_t gv = (size_t)b * a.n_vecs_total + blk.out_vec0;
+        double *Pout = a.P + gv * NP;
+        if (blk.first) {
+            if (r == 0) {
+#pragma unroll
+                for (int K = 0; K < NT; ++K)
+                    if (4 * K + q < a.N) Pout[4 * K + q] = P[K][0];
+            }
+            if (q == 0 && r == 0) a.EX[gv] = ex;
+        } else {
+#pragma unroll
+            for (int K = 0; K < NT; ++K)
+#pragma unroll
+                for (int J = 0; J < NT; ++J) {
+                    const int i = 4 * K + q, c = 4 * J + r;
+                    if (i < a.N && c < a.N) Pout[(size_t)i * NP + c] = P[K][J];
+                }
+            if (q == 0) {
+#pragma unroll
+                for (int J = 0; J < NT; ++J)
+                    if (4 * J + r < a.N) a.EX[gv + 4 * J + r] = ex;
+            }
+        }
+    }
+}

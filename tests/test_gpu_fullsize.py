@@ -118,7 +118,7 @@ def test_config3_slice_32_chunks_of_1e7(hmm_params, oracle):
     fw = [Forwarder.from_array(c, 3) for c in chunks]
     h = [f.handle for f in fw]
     per = forward_chunks_batch(h, pi[None], T[None], E[None], per_chunk=True)[0]
-    assert "k_zpropagate3" in _capi.last_plan()["kernels"]
+    assert any(k in _capi.last_plan()["kernels"] for k in ("k_zpropagate3", "k_zpropagate4"))   # the blocked MFMA kernels
     tot = forward_chunks(h, pi, T, E)
     s = 0.0
     for v in per:

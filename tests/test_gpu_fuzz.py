@@ -37,7 +37,9 @@ def test_random_dispatch(oracle, case):
                                        9000 if heavy else 250000], size=int(rng.integers(1, 5)))]
     hmms = [synth.random_hmm(n, nsym, seed=case * 10 + b, stay=float(rng.choice([0.5, 0.9, 0.999]))) for b in range(B)]
     chunks = [_chunk(rng, nsym, x) for x in lens]
-    try:
+    variant = int(rng.choice([2, 3, 4, 5, 5]))           # form of the register-blocked kernel (N <= 24): VALU, MFMA + LDS table,
+    try:                                                 # automatic, hybrid table wherever possible
+        _capi.check(L.imc_set_blocked_kernel(variant))
         _capi.check(L.imc_set_compression(mode))
         _capi.check(L.imc_dictionary_reset())
         _capi.check(L.imc_set_segment_length(seg))
@@ -46,13 +48,14 @@ def test_random_dispatch(oracle, case):
                                    np.stack([h[2] for h in hmms]), per_chunk=True)
         kernels = _capi.last_plan()["kernels"]
     finally:
+        L.imc_set_blocked_kernel(4)
         L.imc_set_compression(1)
         L.imc_set_segment_length(0)
     for b in range(B):
         for f, c in enumerate(chunks):
             want = oracle.forward_scaled(*hmms[b], c)
             g = got[b, f]
-            assert (g == 0.0 and want == 0.0) or rel_err(g, want) < 1e-11, (case, n, nsym, mode, seg, B, lens, kernels, b, f, g, want)
+            assert (g == 0.0 and want == 0.0) or rel_err(g, want) < 1e-11, (case, n, nsym, mode, variant, seg, B, lens, kernels, b, f, g, want)
 
 
 @pytest.mark.parametrize("case", range(max(40, N_CASES // 4)))

@@ -62,7 +62,7 @@ SCRIPT = textwrap.dedent('''
             L.imc_set_compression(mode); L.imc_dictionary_reset()
             fw = [Forwarder.from_array(c, 3) for c in chunks]
             L.imc_set_segment_length(seg)
-            for variant in ((2, 3) if n <= 24 else (3,)):
+            for variant in ((2, 3, 5) if n <= 24 else (4,)):
                 L.imc_set_blocked_kernel(variant)
                 per = forward_chunks_batch([h.handle for h in fw], pis, Ts, Es, per_chunk=True)
                 for b in range(B):
@@ -71,7 +71,7 @@ SCRIPT = textwrap.dedent('''
                         assert (per[b][k] == 0.0 and w == 0.0) or rel(per[b][k], w) < 1e-11, (n, mode, variant, b, k, per[b][k], w)
             L.imc_set_segment_length(0)
             del fw
-        L.imc_set_blocked_kernel(3); L.imc_set_compression(1)
+        L.imc_set_blocked_kernel(4); L.imc_set_compression(1)
     ragged = [0, 1, 17, 33, 1000, 4097, 70001, 40000]
     check(20, ragged, (0, 1, 2, 3, 4, 5))
     check(10, ragged, (1, 3, 5), seg=64)

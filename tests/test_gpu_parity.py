@@ -37,17 +37,19 @@ def set_zip(mode, reset=True):
         _capi.check(L.imc_dictionary_reset())
 
 
-@pytest.fixture(params=[4, 5, 0, 2, 3, 1, 13, 15],
-                ids=["raw-vector", "raw-blocked", "raw-auto", "token-vector", "token-blocked", "auto", "token-blocked-valu", "raw-blocked-valu"])
+@pytest.fixture(params=[4, 5, 0, 2, 3, 1, 13, 15, 23, 33],
+                ids=["raw-vector", "raw-blocked", "raw-auto", "token-vector", "token-blocked", "auto", "token-blocked-valu",
+                     "raw-blocked-valu", "token-blocked-lds", "token-blocked-hybrid"])
 def zipmode(request):
     """Run a test on the per-column kernel, on each pinned token-kernel variant and with automatic choice.  Modes 3 / 5
-    pin the register-blocked kernel, by default its fp64-MFMA form (k_zpropagate3); 13 / 15 are the same modes with
-    the VALU / DPP form (k_zpropagate2) selected."""
-    valu = request.param >= 10
-    _capi.check(_capi.lib().imc_set_blocked_kernel(2 if valu else 3))
+    pin the register-blocked kernel, by default its fp64-MFMA form (k_zpropagate3 / k_zpropagate4, chosen by cost);
+    13 / 15 are the same modes with the VALU / DPP form (k_zpropagate2), 23 pins the LDS-table MFMA kernel, 33 the
+    hybrid-table one wherever the dictionary has a level beyond LDS."""
+    variant = {0: 4, 1: 2, 2: 3, 3: 5}[request.param // 10]
+    _capi.check(_capi.lib().imc_set_blocked_kernel(variant))
     set_zip(request.param % 10)
     yield request.param % 10
-    _capi.check(_capi.lib().imc_set_blocked_kernel(3))
+    _capi.check(_capi.lib().imc_set_blocked_kernel(4))
     set_zip(1)
 
 
@@ -635,3 +637,41 @@ def test_forwarder_attributes_of_the_reference(example_pairs):
     assert np.array_equal(back, obs)
     short = Forwarder.from_array(obs[:100], 3)                     # too short to compress: the raw stream itself
     assert short.new_nsyms == 3 and short.sym2pair == {} and np.array_equal(short.new_obs, obs[:100])
+
+
+@pytest.mark.parametrize("n", [4, 8, 10, 13, 16, 20])
+@pytest.mark.parametrize("seg", [0, 52, 1000])
+def test_hybrid_table_kernel(oracle, n, seg):
+    """k_zpropagate4: a dictionary level far beyond what LDS holds (up to 256 tokens), operators in a global table, the
+    hottest cached in LDS, the others streamed a step ahead.  Long compressible chunks so that the dictionary grows
+    past LDS; ragged / tiny / empty chunks ride along; two parameter sets; forced segment lengths that are not
+    multiples of 16 (the masked first / last blocks) and 4-token granularity."""
+    L = _capi.lib()
+    hmms = [synth.random_hmm(n, 3, seed=4000 + n + b, stay=0.995) for b in range(2)]
+    pis, Ts, Es = (np.stack([h[k] for h in hmms]) for k in range(3))
+    chunks = [synth.sample_alignment(pis[0], Ts[0], Es[0], m, seed=70 + k) for k, m in enumerate((1_500_000, 0, 1, 37, 4099, 300_000))]
+    want = [[oracle.forward_scaled(pis[b], Ts[b], Es[b], c) for c in chunks] for b in range(2)]
+    try:
+        set_zip(3)                                        # pinned: register-blocked kernel, fresh dictionary
+        _capi.check(L.imc_set_blocked_kernel(5))          # hybrid table wherever a level beyond LDS exists
+        fw = [Forwarder.from_array(c, 3) for c in chunks]
+        assert fw[0].compressed_length(256)[1] > 128      # the dictionary did grow
+        set_seg(seg)
+        got = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+        kernels = _capi.last_plan()["kernels"]
+        if n > 8:                                         # (up to N = 8 every byte level fits LDS: plain k_zpropagate3)
+            assert "k_zpropagate4" in kernels, kernels
+        again = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+        assert np.array_equal(got, again)                 # bit-identical repeats
+        _capi.check(L.imc_set_blocked_kernel(3))          # the LDS-table kernel on the same chunks agrees
+        lds = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+        assert "k_zpropagate3" in _capi.last_plan()["kernels"]
+    finally:
+        set_seg(0)
+        _capi.check(L.imc_set_blocked_kernel(4))
+        set_zip(1)
+    for b in range(2):
+        for k in range(len(chunks)):
+            w = want[b][k]
+            assert (got[b][k] == 0.0 and w == 0.0) or rel_err(got[b][k], w) < TOL, (n, seg, b, k, got[b][k], w)
+            assert (lds[b][k] == 0.0 and w == 0.0) or rel_err(lds[b][k], w) < TOL
