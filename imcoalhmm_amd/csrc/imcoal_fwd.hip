@@ -29,6 +29,7 @@
 #include <cstring>
 #include <list>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -403,7 +404,8 @@ struct KernelChoice {
     size_t (*zip3_lds)(int) = nullptr;
     bool zip3_attr_set = false;
     void (*zip4)(BigArgs) = nullptr;   // ... with the hybrid LDS / L2 operator table, and the kernel that builds that table
-    void (*zip4_table)(BigArgs) = nullptr;
+    void (*zip4_raw)(BigArgs) = nullptr;
+    void (*zip4_level)(BigArgs, int, int) = nullptr;
     size_t (*zip4_lds)(int, int) = nullptr;
     int (*zip4_max_hot)(int, size_t) = nullptr;
     int tok_doubles = 0;               // doubles per table entry of the MFMA kernels
@@ -427,7 +429,8 @@ KernelChoice make_kc()
         k.tok_doubles = Zip3Geom<NP / 4>::TOK;
         if constexpr (NP <= 20) {   // (NP = 24: the extra 36 operand registers of the hybrid form would spill)
             k.zip4 = k_zpropagate4<NP / 4>;
-            k.zip4_table = k_z4_table<NP / 4>;
+            k.zip4_raw = k_z4_raw<NP / 4>;
+            k.zip4_level = k_z4_level<NP / 4>;
             k.zip4_lds = &Zip4Geom<NP / 4>::lds_bytes;
             k.zip4_max_hot = &Zip4Geom<NP / 4>::max_hot;
         }
@@ -497,6 +500,7 @@ struct Group {             // one propagate launch
     uint16_t *d_hot = nullptr;
     uint16_t *d_tab_order = nullptr;          // blocked MFMA kernel: merged tokens of the alphabet by dictionary depth
     int *d_tab_lvl = nullptr;
+    std::vector<int> tab_lvl;                 // host copy of the depth offsets
     int tab_nlvl = 0;
     double *d_Ctab = nullptr;
     int *d_cex = nullptr;
@@ -733,7 +737,8 @@ struct PlanBuilder {
                             uint64_t all = 0, top = 0;
                             for (size_t z = 0; z < sorted.size(); ++z) { all += sorted[z]; if ((int)z < std::min(max_hot, A)) top += sorted[z]; }
                             const double cold = all ? 1.0 - (double)top / (double)all : 0.0;
-                            cost = passes * 2.3 + 7.0 + steps * t_step * (1.0 + 0.12 * cold);
+                            const double depths = (double)std::max<int>(1, (int)std::set<int>(kv.first->depth.begin() + o0->nsym, kv.first->depth.begin() + A).size());
+                            cost = depths * 5.0 + 10.0 + steps * t_step * (1.0 + 0.12 * cold);   // one ~5 us launch per depth
                         }
                         if (g.blocked_variant == 5 && !fits) cost *= 1e-3;      // tests: the hybrid table wherever it is possible
                         if (cost < best) { best = cost; best_l = l; }
@@ -1109,6 +1114,7 @@ struct PlanBuilder {
                 }
                 lvl.push_back((int)order.size());
                 gr.tab_nlvl = order.empty() ? 0 : (int)lvl.size() - 1;
+                gr.tab_lvl = lvl;
                 e = up((void **)&gr.d_tab_order, order.data(), order.size() * sizeof(uint16_t));
                 if (e == hipSuccess) e = up((void **)&gr.d_tab_lvl, lvl.data(), lvl.size() * sizeof(int));
             }
@@ -1401,8 +1407,13 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                 // hybrid table: one workgroup per parameter set builds the operators in global memory (they stay in
                 // L2), then the scan caches the hot ones in LDS and streams the rest a step ahead
                 ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex;
-                hipLaunchKernelGGL(kc->zip4_table, dim3(1, (unsigned)B), dim3(Z2WAVES * 64), (size_t)(5 * gr.A + 16) * 4, stream, ba);
+                hipLaunchKernelGGL(kc->zip4_raw, dim3((unsigned)S + 1, (unsigned)B), dim3(256), 0, stream, ba);
                 HIP_TRY(hipGetLastError());
+                for (int d = 0; d < gr.tab_nlvl; ++d) {   // one launch per dictionary depth: kernel boundaries order the depths
+                    const int first = gr.tab_lvl[d], count = gr.tab_lvl[d + 1] - first;
+                    hipLaunchKernelGGL(kc->zip4_level, dim3((unsigned)(count + 3) / 4, (unsigned)B), dim3(64), 0, stream, ba, first, count);
+                    HIP_TRY(hipGetLastError());
+                }
                 if (!kc->zip4_attr_set) {
                     HIP_TRY(hipFuncSetAttribute((const void *)kc->zip4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
                     kc->zip4_attr_set = true;

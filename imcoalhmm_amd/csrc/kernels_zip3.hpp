@@ -86,7 +86,9 @@ __device__ __forceinline__ void zip3_step(const double (&Pin)[NT][NT], double (&
 }
 
 // common power-of-two rescale of a segment's operator: exponent of its largest entry over the segment's 16 lanes
-// (lanes 16 q + 4 blk + r: the xor partners 1, 2, 16, 32 stay inside the block)
+// (lanes 16 q + 4 blk + r: the xor partners 1, 2, 16, 32 stay inside the block).  The largest entry's exponent is the
+// largest exponent, so the cross-lane part reduces one int per lane instead of a double; a lane whose maximum is not a
+// positive finite number (0, inf, NaN) votes "leave the operator alone", which wins (same rule as before).
 template <int NT>
 __device__ __forceinline__ void zip3_rescale(double (&P)[NT][NT], int &ex)
 {
@@ -95,14 +97,13 @@ __device__ __forceinline__ void zip3_rescale(double (&P)[NT][NT], int &ex)
     for (int K = 0; K < NT; ++K)
 #pragma unroll
         for (int J = 0; J < NT; ++J) mx = (P[K][J] > mx || P[K][J] != P[K][J]) ? P[K][J] : mx;
-#pragma unroll
-    for (int m = 1; m <= 32; m = (m == 2 ? 16 : m * 2)) {
-        const double o = __shfl_xor(mx, m, 64);
-        mx = (o > mx || o != o) ? o : mx;
-    }
     int e = 0;
     (void)frexp(mx, &e);
-    e = (mx > 0.0 && mx < INFINITY) ? e : 0;
+    const bool zero = mx == 0.0;                       // an all-zero lane (padding rows, first-segment columns) abstains
+    e = zero ? INT_MIN : (mx > 0.0 && mx < INFINITY) ? e : INT_MAX;
+#pragma unroll
+    for (int m = 1; m <= 32; m = (m == 2 ? 16 : m * 2)) e = max(e, __shfl_xor(e, m, 64));
+    e = (e == INT_MAX || e == INT_MIN) ? 0 : e;
 #pragma unroll
     for (int K = 0; K < NT; ++K)
 #pragma unroll

@@ -3,9 +3,8 @@
 // that fit), its operators in a global table that stays in L2 (256 x 3.2 KB = 0.8 MB), the most frequent ones also
 // cached in LDS.  Included by imcoal_fwd.hip only.
 //
-//   * k_z4_table<NT>: one workgroup per parameter set builds the table in global memory, one dictionary depth at a
-//     time with the MFMA step itself (four tokens per wavefront, as in k_zpropagate3's prologue; operands gathered
-//     from the table's lower depths in L2).
+//   * k_z4_raw / k_z4_level<NT>: the table in global memory, one launch per dictionary depth, each token the MFMA step
+//     itself on its children's entries (four tokens per wavefront, as in k_zpropagate3's prologue).
 //   * k_zpropagate4<NT>: k_zpropagate3's scan.  Every workgroup copies the H hottest operators (+ the identity) from
 //     the global table into LDS.  A step whose token is hot reads its A operands from LDS one tile-row ahead, exactly
 //     as k_zpropagate3; a step whose token is cold takes them from 25 registers per lane that were loaded from the
@@ -61,74 +60,66 @@ __device__ __forceinline__ void zip4_load_row_global(double (&a)[NT], const doub
 }
 
 // ---- the global table ---------------------------------------------------------------------------------------------
-// a.Ctab: [B][A + 1][TOK] (entry A = identity), a.cex: [B][A + 1].  One workgroup per parameter set.
+// a.Ctab: [B][A + 1][TOK] (entry A = identity), a.cex: [B][A + 1].  k_z4_raw writes the raw symbols' operators and the
+// identity; k_z4_level, launched once per dictionary depth, builds that depth's merged tokens - one MFMA block per
+// token, four per wavefront, one wavefront per workgroup so that a depth's ~10-70 tokens spread over as many CUs - from
+// its children's entries, which earlier launches left in L2.  A depth is latency, not work (children in, 125 MFMAs,
+// rescale, entry out: ~3.5 us), and plain kernel boundaries turned out to be the cheapest way to order the depths:
+// a single-workgroup build with barriers (with or without forwarding fresh operators through LDS) took 72-82 us for
+// 253 tokens in 10 depths, because every pass then serialises behind the slowest of eight wavefronts' latency chains.
 template <int NT>
-__global__ __launch_bounds__(Z2WAVES * 64) void k_z4_table(BigArgs a)
+__global__ __launch_bounds__(256) void k_z4_raw(BigArgs a)
 {
     using Geo = Zip3Geom<NT>;
-    constexpr int NP = Geo::NP, TOK = Geo::TOK, THREADS = Z2WAVES * 64;
-    extern __shared__ __attribute__((aligned(16))) int lds_i[];
-    int *m_cex = lds_i;                         // [A + 1]
-    int *m_left = m_cex + a.A + 1, *m_right = m_left + a.A, *m_order = m_right + a.A, *m_lvl = m_order + a.A;   // [A] x3, [A + 2]
-    const int tid = threadIdx.x, b = blockIdx.y;
+    constexpr int NP = Geo::NP, TOK = Geo::TOK;
+    const int b = blockIdx.y, sidx = blockIdx.x;                    // one workgroup per raw symbol, one more for the identity
     const double *pp = a.params + (size_t)b * a.pstride;
     const double *Tp = pp + a.PP;
     const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
     double *Gt = a.Ctab + (size_t)b * (a.A + 1) * TOK;
-    const int IDENT = a.A;
-    for (int idx = tid; idx < (a.S + 1) * NP * NP; idx += THREADS) {
-        const int sidx = idx / (NP * NP);
-        const int rem = idx - sidx * NP * NP;
-        const int i = rem / NP, j = rem - i * NP;
-        if (sidx < a.S) Gt[(size_t)sidx * TOK + Geo::idx(i, j)] = Etg[(size_t)sidx * a.PP + i] * Tp[(size_t)j * a.PP + i];
-        else Gt[(size_t)IDENT * TOK + Geo::idx(i, j)] = i == j ? 1.0 : 0.0;
+    int *Gc = a.cex + (size_t)b * (a.A + 1);
+    const int entry = sidx < a.S ? sidx : a.A;
+    for (int idx = threadIdx.x; idx < NP * NP; idx += blockDim.x) {
+        const int i = idx / NP, j = idx - i * NP;
+        Gt[(size_t)entry * TOK + Geo::idx(i, j)] = sidx < a.S ? Etg[(size_t)sidx * a.PP + i] * Tp[(size_t)j * a.PP + i] : (i == j ? 1.0 : 0.0);
     }
-    if (tid < a.S) m_cex[tid] = 0;
-    if (tid == 0) m_cex[IDENT] = 0;
-    for (int z = a.S + tid; z < a.A; z += THREADS) { m_left[z] = a.tok_left[z]; m_right[z] = a.tok_right[z]; }
-    for (int k = tid; k < a.A - a.S && a.tab_nlvl > 0; k += THREADS) m_order[k] = a.tab_order[k];
-    for (int k = tid; k <= a.tab_nlvl && a.tab_nlvl > 0; k += THREADS) m_lvl[k] = a.tab_lvl[k];
-    __threadfence_block();
-    __syncthreads();
-    const int lane = tid & 63, wv = tid >> 6;
+    if (threadIdx.x == 0) Gc[entry] = 0;
+}
+
+template <int NT>
+__global__ __launch_bounds__(64) void k_z4_level(BigArgs a, int first, int count)
+{
+    using Geo = Zip3Geom<NT>;
+    constexpr int TOK = Geo::TOK;
+    const int b = blockIdx.y, lane = threadIdx.x;
     const int q = lane >> 4, bq = (lane >> 2) & 3, r = lane & 3;
     const int lo = (q * 4 + r) * Geo::NTE, lx = q * 4 + r;
-    for (int d = 0; d < a.tab_nlvl; ++d) {
-        const int o0 = m_lvl[d], o1 = m_lvl[d + 1];
-        for (int base = o0; base < o1; base += Z2SLOTS) {
-            if (base + wv * 4 >= o1) continue;               // nothing for this wavefront (wavefront-uniform)
-            const int ti = base + wv * 4 + bq;
-            const bool have = ti < o1;
-            const int z = have ? m_order[ti] : IDENT;
-            const int zl = have ? m_left[z] : IDENT, zr = have ? m_right[z] : IDENT;
-            const double *Gl = Gt + (size_t)zl * TOK, *Gr = Gt + (size_t)zr * TOK;
-            double Bt[NT][NT], Ar[NT][NT], Out[NT][NT];
-#pragma unroll
-            for (int K = 0; K < NT; ++K)
-#pragma unroll
-                for (int J = 0; J < NT; ++J) Bt[K][J] = Gl[Geo::idx(4 * K + q, 4 * J + r)];
-#pragma unroll
-            for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(Ar[I], Gr, I, lo, lx);
-            zip4_step_regs<NT>(Bt, Out, Ar);
-            int e2 = 0;
-            zip3_rescale<NT>(Out, e2);
-            if (have) {
-                double *Gz = Gt + (size_t)z * TOK;
-#pragma unroll
-                for (int K = 0; K < NT; ++K)
-#pragma unroll
-                    for (int J = 0; J < NT; ++J) Gz[Geo::idx(4 * K + q, 4 * J + r)] = Out[K][J];
-                if (q == 0 && r == 0) m_cex[z] = m_cex[zl] + m_cex[zr] + e2;
-            }
-        }
-        // the next depth's wavefronts (same workgroup, same CU) read what this depth stored: stores are complete at the
-        // barrier, and no line of these entries can have been cached before it was written (each entry - a whole number
-        // of 128-byte lines - is written once per launch, before its first read)
-        __threadfence_block();
-        __syncthreads();
-    }
+    double *Gt = a.Ctab + (size_t)b * (a.A + 1) * TOK;
     int *Gc = a.cex + (size_t)b * (a.A + 1);
-    for (int z = tid; z <= a.A; z += THREADS) Gc[z] = m_cex[z];
+    const int ti = blockIdx.x * 4 + bq;
+    const bool have = ti < count;
+    const int z = have ? (int)a.tab_order[first + ti] : a.A;          // (an idle block multiplies identities)
+    const int zl = have ? (int)a.tok_left[z] : a.A, zr = have ? (int)a.tok_right[z] : a.A;
+    const double *Gl = Gt + (size_t)zl * TOK, *Gr = Gt + (size_t)zr * TOK;
+    double Bt[NT][NT], Ar[NT][NT], Out[NT][NT];
+#pragma unroll
+    for (int K = 0; K < NT; ++K)
+#pragma unroll
+        for (int J = 0; J < NT; ++J) Bt[K][J] = Gl[Geo::idx(4 * K + q, 4 * J + r)];
+#pragma unroll
+    for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(Ar[I], Gr, I, lo, lx);
+    const int cel = Gc[zl], cer = Gc[zr];
+    zip4_step_regs<NT>(Bt, Out, Ar);
+    int e2 = 0;
+    zip3_rescale<NT>(Out, e2);
+    if (have) {
+        double *Gz = Gt + (size_t)z * TOK;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) Gz[Geo::idx(4 * K + q, 4 * J + r)] = Out[K][J];
+        if (q == 0 && r == 0) Gc[z] = cel + cer + e2;
+    }
 }
 
 // ---- the scan -----------------------------------------------------------------------------------------------------
