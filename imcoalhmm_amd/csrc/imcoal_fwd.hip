@@ -74,6 +74,8 @@ constexpr size_t DICT_TRAIN_MAX = 8u << 20;        // byte tokens (< 256): train
 constexpr size_t DICT_WIDE_TRAIN_TOKENS = 1u << 19; // 16-bit tokens: train on at most this many byte-level tokens (~4e7 columns)
 constexpr size_t DICT_WIDE_MIN_COUNT = 6;          // ... in which a pair must occur this often
 constexpr size_t CTAB_BUDGET = (size_t)24 << 30;   // largest operator table (all parameter sets) a plan may allocate
+constexpr int HYBRID_MAX_ALPHABET = 1024;          // hybrid table (k_zpropagate4): largest dictionary level considered (3.3 MB of
+                                                   // operators at N = 20: still resident in every XCD's 4 MB L2)
 constexpr size_t Z2GRAN = 4;                       // blocked kernels: segment lengths are multiples of this many tokens
 constexpr size_t R1_MIN_SEGLEN = 1024;             // rank-one hand-off: segments at least this long (stream elements) ...
 constexpr size_t R1_MIN_HEAD = 256;                // ... run at least this many on the GEMM chain before the test
@@ -359,6 +361,9 @@ int obs_upload(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym
             if (!enc.is_wide[l]) {
                 o->tok_count[l].assign((size_t)enc.alphabet[l], 0u);
                 for (size_t t = 1; t < enc.length[l]; ++t) o->tok_count[l][enc.bytes[l][t]]++;   // (position 0 is a raw symbol)
+            } else if (enc.alphabet[l] <= HYBRID_MAX_ALPHABET) {
+                o->tok_count[l].assign((size_t)enc.alphabet[l], 0u);
+                for (size_t t = 1; t < enc.length[l]; ++t) o->tok_count[l][enc.wide[l][t]]++;
             }
             hipError_t e3 = enc.is_wide[l]
                 ? upload_padded(reinterpret_cast<const uint8_t *>(enc.wide[l].data()), enc.length[l] * sizeof(imc::tok_t), &o->d_tok[l])
@@ -403,13 +408,14 @@ struct KernelChoice {
     void (*zip3)(BigArgs) = nullptr;   // ... its fp64-MFMA form (same launch geometry and block list)
     size_t (*zip3_lds)(int) = nullptr;
     bool zip3_attr_set = false;
-    void (*zip4)(BigArgs) = nullptr;   // ... with the hybrid LDS / L2 operator table, and the kernel that builds that table
+    void (*zip4)(BigArgs) = nullptr;   // ... with the hybrid LDS / L2 operator table, and the kernels that build that table
+    void (*zip4w)(BigArgs) = nullptr;  // ... on 16-bit token streams (dictionary levels beyond 256 tokens)
     void (*zip4_raw)(BigArgs) = nullptr;
     void (*zip4_level)(BigArgs, int, int) = nullptr;
     size_t (*zip4_lds)(int, int) = nullptr;
     int (*zip4_max_hot)(int, size_t) = nullptr;
     int tok_doubles = 0;               // doubles per table entry of the MFMA kernels
-    bool zip4_attr_set = false;
+    bool zip4_attr_set = false, zip4w_attr_set = false;
     // the blocked kernel in use (g.blocked_variant) and its LDS need for an alphabet of A tokens
     bool use3() const;
     size_t blocked_lds(int A) const { return use3() ? zip3_lds(A) : zip2_lds(A); }
@@ -428,7 +434,8 @@ KernelChoice make_kc()
         k.zip3_lds = &Zip3Geom<NP / 4>::lds_bytes;
         k.tok_doubles = Zip3Geom<NP / 4>::TOK;
         if constexpr (NP <= 20) {   // (NP = 24: the extra 36 operand registers of the hybrid form would spill)
-            k.zip4 = k_zpropagate4<NP / 4>;
+            k.zip4 = k_zpropagate4<NP / 4, false>;
+            k.zip4w = k_zpropagate4<NP / 4, true>;
             k.zip4_raw = k_z4_raw<NP / 4>;
             k.zip4_level = k_z4_level<NP / 4>;
             k.zip4_lds = &Zip4Geom<NP / 4>::lds_bytes;
@@ -478,8 +485,8 @@ KernelChoice *choose_kernel(int N, bool prefer_gemm)
 
 void reset_kernel_attributes()
 {
-    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.plain_attr_set = false;
-    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.plain_attr_set = false;
+    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.zip4w_attr_set = k.plain_attr_set = false;
+    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.zip4w_attr_set = k.plain_attr_set = false;
 }
 
 // ---- launch plan ----------------------------------------------------------------------------------
@@ -495,6 +502,7 @@ struct Group {             // one propagate launch
     uint32_t *d_seg_ids = nullptr, *d_seg_out = nullptr;
     Z2Block *d_blocks = nullptr;
     bool zip4 = false;                        // blocked MFMA kernel with the hybrid table: alphabet beyond LDS, n_hot operators cached
+    bool wide_tokens = false;                 // ... its token stream holds 16-bit ids
     int n_hot = 0;
     std::vector<uint16_t> hot;
     uint16_t *d_hot = nullptr;
@@ -711,8 +719,8 @@ struct PlanBuilder {
                         // that fit LDS run k_zpropagate3; byte levels beyond that can run k_zpropagate4 (hybrid table:
                         // one workgroup builds it in L2, steps on tokens outside the LDS-cached hot set cost ~12 % more).
                         const int A = o0->alphabet[l];
-                        if (!(A > o0->nsym && A <= imc::kByteAlphabet && o0->d_tok[l]) || o0->wide[l]) continue;
-                        const bool fits = kc->blocked_lds(A) <= LDS_BUDGET;
+                        if (!(A > o0->nsym && A <= HYBRID_MAX_ALPHABET && o0->d_tok[l]) || o0->wide_raw) continue;
+                        const bool fits = !o0->wide[l] && kc->blocked_lds(A) <= LDS_BUDGET;   // (k_zpropagate3 reads byte streams)
                         const int max_hot = kc->zip4 ? kc->zip4_max_hot(A, LDS_BUDGET) : 0;
                         const bool hybrid_ok = !fits && kc->zip4 && g.blocked_variant >= 4 && max_hot >= 8 && !o0->tok_count[l].empty();
                         if (!fits && !hybrid_ok) continue;
@@ -768,9 +776,10 @@ struct PlanBuilder {
                 if (const char *fl = std::getenv("IMC_FORCE_LEVEL")) {   // experiments only: pin the dictionary level index
                     const int l = std::atoi(fl);
                     const imc_obs *o0 = chunks[kv.second[0]];
-                    const int amax_forced = mfma_blocked && kc->zip4 && g.blocked_variant >= 4 ? imc::kByteAlphabet : a_max;
+                    const bool hybrid = mfma_blocked && kc->zip4 && g.blocked_variant >= 4 && !o0->wide_raw;
+                    const int amax_forced = hybrid ? HYBRID_MAX_ALPHABET : a_max;
                     if (l >= 0 && l < imc::kNumLevels && o0->alphabet[l] <= amax_forced && o0->alphabet[l] > o0->nsym && o0->d_tok[l] &&
-                        !(mfma_blocked && o0->wide[l])) best_l = l;
+                        (hybrid ? !o0->tok_count[l].empty() : !o0->wide[l])) best_l = l;
                 }
                 dict_level[kv.first] = best_l;
             }
@@ -796,7 +805,8 @@ struct PlanBuilder {
                 gr.A = S;
                 if (gr.zip) { gr.dict = o->dict; gr.A = o->alphabet[level]; }
                 // an alphabet beyond LDS can only have been chosen for the hybrid-table kernel
-                gr.zip4 = gr.zip && mfma_blocked && kc->blocked_lds(gr.A) > LDS_BUDGET;
+                gr.zip4 = gr.zip && mfma_blocked && (kc->blocked_lds(gr.A) > LDS_BUDGET || o->wide[level]);
+                gr.wide_tokens = gr.zip && o->wide[level];
                 p->groups.push_back(gr);
                 gi = (int)p->groups.size() - 1;
             }
@@ -1183,6 +1193,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     for (int f = 0; f < n_chunks; ++f) key.push_back(chunks[f]->id);
     key.push_back((uint64_t)N); key.push_back((uint64_t)S); key.push_back((uint64_t)B);
     key.push_back((uint64_t)g.seg_override); key.push_back((uint64_t)(g.compression * 4 + g.kernel_pref + (op_mode ? 64 : 0) + g.blocked_variant * 128));
+    { const char *fl = std::getenv("IMC_FORCE_LEVEL"); key.push_back(fl ? (uint64_t)(std::atoi(fl) + 1) : 0u); }   // (experiments / tests)
     for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
         if ((*it)->key == key) {
             g_plans.splice(g_plans.begin(), g_plans, it);
@@ -1414,13 +1425,15 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                     hipLaunchKernelGGL(kc->zip4_level, dim3((unsigned)(count + 3) / 4, (unsigned)B), dim3(64), 0, stream, ba, first, count);
                     HIP_TRY(hipGetLastError());
                 }
-                if (!kc->zip4_attr_set) {
-                    HIP_TRY(hipFuncSetAttribute((const void *)kc->zip4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
-                    kc->zip4_attr_set = true;
+                void (*scan)(BigArgs) = gr.wide_tokens ? kc->zip4w : kc->zip4;
+                bool &attr4 = gr.wide_tokens ? kc->zip4w_attr_set : kc->zip4_attr_set;
+                if (!attr4) {
+                    HIP_TRY(hipFuncSetAttribute((const void *)scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+                    attr4 = true;
                 }
-                hipLaunchKernelGGL(kc->zip4, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64),
+                hipLaunchKernelGGL(scan, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64),
                                    kc->zip4_lds(gr.A, gr.n_hot), stream, ba);
-                note(std::string("k_zpropagate4<") + std::to_string(NP / 4) + ">" + strm);
+                note(std::string("k_zpropagate4<") + std::to_string(NP / 4) + (gr.wide_tokens ? ",16>" : ">") + strm);
                 lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A);
                 HIP_TRY(hipGetLastError());
                 continue;

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
             return (u < live && u != dead0 && u < RESCALE_EVERY) ? tk : IDENT;
         };
         zip3_load_row<NT>(arow, C + (size_t)tok_of(0) * TOK, 0, lo, lx);
+#pragma unroll 1
         for (int u = 0; u < npos; u += 2) two_steps(tok_of(u), tok_of(u + 1), tok_of(u + 2));
         zip3_rescale<NT>(P, ex);
     };

@@ -123,29 +123,31 @@ __global__ __launch_bounds__(64) void k_z4_level(BigArgs a, int first, int count
 }
 
 // ---- the scan -----------------------------------------------------------------------------------------------------
-struct Z4Tok {              // one step's operator for this lane's segment
-    int s;                  // LDS slot (0 when cold: a valid address whose data is not used)
+struct Z4Tok {              // one step's operator for this lane's segment (kept small: five of them are live in the loop)
+    int s;                  // LDS slot, or -1: not cached in LDS - operands come from the registers loaded from the global table
     int ce;                 // its power-of-two exponent
-    bool cold;              // not cached in LDS: operands come from the registers loaded from the global table
-    const double *g;        // its global table entry
+    int tok;                // its token id = index of its global table entry
 };
 
 // Pout <- C_cur * Pin.  `al` holds tile-row 0 of cur's LDS entry on entry and of nxt's on exit (as zip3_step);
 // `pre` holds ALL tile-rows of cur's global entry if cur is cold, and is refilled tile-row by tile-row with nxt's
 // entry (if that is cold) as soon as each row has been consumed.
 template <int NT>
-__device__ __forceinline__ void zip4_step(const double (&Pin)[NT][NT], double (&Pout)[NT][NT], const double *C, const Z4Tok &cur,
-                                          const Z4Tok &nxt, double (&al)[NT], double (&pre)[NT][NT], int lo, int lx)
+__device__ __forceinline__ void zip4_step(const double (&Pin)[NT][NT], double (&Pout)[NT][NT], const double *C, const double *Gt,
+                                          const Z4Tok &cur, const Z4Tok &nxt, double (&al)[NT], double (&pre)[NT][NT], int lo, int lx)
 {
     constexpr int TOK = Zip3Geom<NT>::TOK;
-    const double *Cz = C + (size_t)cur.s * TOK, *Cn = C + (size_t)nxt.s * TOK;
+    // (a cold token reads LDS slot 0: a valid address whose data is not used)
+    const double *Cz = C + (size_t)max(cur.s, 0) * TOK, *Cn = C + (size_t)max(nxt.s, 0) * TOK;
+    const double *Gn = Gt + (size_t)nxt.tok * TOK;
+    const bool cur_cold = cur.s < 0, nxt_cold = nxt.s < 0;
 #pragma unroll
     for (int I = 0; I < NT; ++I) {
         double an[NT], av[NT];
         if (I + 1 < NT) zip3_load_row<NT>(an, Cz, I + 1, lo, lx);
         else zip3_load_row<NT>(an, Cn, 0, lo, lx);
 #pragma unroll
-        for (int K = 0; K < NT; ++K) av[K] = cur.cold ? pre[I][K] : al[K];
+        for (int K = 0; K < NT; ++K) av[K] = cur_cold ? pre[I][K] : al[K];
         __builtin_amdgcn_sched_barrier(0);         // keep the LDS prefetch ahead of this tile-row's MFMAs
 #pragma unroll
         for (int K = 0; K < NT; ++K)
@@ -153,15 +155,17 @@ __device__ __forceinline__ void zip4_step(const double (&Pin)[NT][NT], double (&
             for (int J = 0; J < NT; ++J)
                 Pout[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[K], Pin[K][J], K == 0 ? 0.0 : Pout[I][J], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (nxt.cold) zip4_load_row_global<NT>(pre[I], nxt.g, I, lo, lx);   // (per lane; a full step ahead of its use)
+        if (nxt_cold) zip4_load_row_global<NT>(pre[I], Gn, I, lo, lx);   // (per lane; a full step ahead of its use)
 #pragma unroll
         for (int K = 0; K < NT; ++K) al[K] = an[K];
     }
 }
 
-template <int NT>
+// WIDE: the token stream holds 16-bit ids (dictionary levels beyond 256 tokens) instead of bytes.
+template <int NT, bool WIDE>
 __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigArgs a)
 {
+    constexpr int TB = WIDE ? 2 : 1;                                   // bytes per token
     using Geo = Zip3Geom<NT>;
     using G4 = Zip4Geom<NT>;
     constexpr int NP = Geo::NP, TOK = Geo::TOK, THREADS = Z2WAVES * 64;
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
 
     double P[NT][NT], Q[NT][NT];
     {
-        const int tok0 = (valid && first) ? (int)tokp[0] : 0;
+        const int tok0 = (valid && first) ? seg_token(tokp, WIDE, 0) : 0;
 #pragma unroll
         for (int K = 0; K < NT; ++K)
 #pragma unroll
@@ -230,74 +234,104 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
         for (int K = 0; K < NT; ++K) pre[I][K] = 0.0;
     auto mk = [&](int tok) __attribute__((always_inline)) {
         Z4Tok t;
-        const int s = slot_of[tok];
-        t.cold = s < 0;
-        t.s = t.cold ? 0 : s;
+        t.s = slot_of[tok];
         t.ce = cex[tok];
-        t.g = Gt + (size_t)tok * TOK;
+        t.tok = tok;
         return t;
     };
     // start (or restart) the pipeline at `c`: its LDS row 0 and, if it is cold, all of its global rows - exposed latency,
     // paid at the start of a segment and where the token of the next position is not known a step ahead
     auto prime = [&](const Z4Tok &c) __attribute__((always_inline)) {
-        zip3_load_row<NT>(al, C + (size_t)c.s * TOK, 0, lo, lx);
-        if (c.cold) {
+        zip3_load_row<NT>(al, C + (size_t)max(c.s, 0) * TOK, 0, lo, lx);
+        if (c.s < 0) {
+            const double *Gc0 = Gt + (size_t)c.tok * TOK;
 #pragma unroll
-            for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(pre[I], c.g, I, lo, lx);
+            for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(pre[I], Gc0, I, lo, lx);
         }
     };
     auto two_steps = [&](const Z4Tok &t0, const Z4Tok &t1, const Z4Tok &tn) __attribute__((always_inline)) {
-        zip4_step<NT>(P, Q, C, t0, t1, al, pre, lo, lx);
-        zip4_step<NT>(Q, P, C, t1, tn, al, pre, lo, lx);
+        zip4_step<NT>(P, Q, C, Gt, t0, t1, al, pre, lo, lx);
+        zip4_step<NT>(Q, P, C, Gt, t1, tn, al, pre, lo, lx);
         ex += t0.ce + t1.ce;
     };
-    // A block of 16 positions in which not every lane's segment has a token (see k_zpropagate3): one 16-byte load per
-    // lane where the segment still has tokens, the identity elsewhere; the pipeline is primed at its first position.
-    auto masked_block = [&](int bi, int npos) __attribute__((always_inline)) {
+    // A block of 16 positions in which not every lane's segment has a token (see k_zpropagate3): per run of PER positions
+    // (one 16-byte load: 16 byte tokens or 8 16-bit ones) the lane loads where its segment still has tokens and steps
+    // with the identity elsewhere; the pipeline is primed at the start of every run.
+    constexpr int PER = WIDE ? 8 : 16;
+    auto masked_run = [&](int bi, int u0, int n) __attribute__((always_inline)) {   // positions u0 .. u0 + n - 1 of block bi, n even
         uint4 ob = make_uint4(0u, 0u, 0u, 0u);
-        if (bi * RESCALE_EVERY < len) ob = *reinterpret_cast<const uint4 *>(tokp + (size_t)bi * RESCALE_EVERY);
-        const int live = len - bi * RESCALE_EVERY;
-        const int dead0 = (first && bi == 0) ? 0 : -1;
+        if (bi * RESCALE_EVERY + u0 < len) ob = *reinterpret_cast<const uint4 *>(tokp + ((size_t)bi * RESCALE_EVERY + u0) * TB);
+        const int live = len - bi * RESCALE_EVERY - u0;                 // run positions v < live hold a token
+        const int dead0 = (first && bi == 0 && u0 == 0) ? 0 : -1;
         const unsigned long long lo64 = (unsigned long long)ob.y << 32 | ob.x, hi64 = (unsigned long long)ob.w << 32 | ob.z;
-        auto tok_of = [&](int u) __attribute__((always_inline)) {
-            const unsigned long long h = u < 8 ? lo64 : hi64;
-            const int tk = (int)((h >> (8 * (u & 7))) & 0xffull);
-            return (u < live && u != dead0 && u < RESCALE_EVERY) ? tk : IDENT;
+        auto tok_of = [&](int v) __attribute__((always_inline)) {
+            const unsigned long long h = v < PER / 2 ? lo64 : hi64;
+            const int tk = WIDE ? (int)((h >> (16 * (v & 3))) & 0xffffull) : (int)((h >> (8 * (v & 7))) & 0xffull);
+            return (v < live && v != dead0 && v < PER) ? tk : IDENT;
         };
         Z4Tok c0 = mk(tok_of(0));
         prime(c0);
-        for (int u = 0; u < npos; u += 2) {
-            const Z4Tok c1 = mk(tok_of(u + 1)), c2 = mk(tok_of(u + 2));
+#pragma unroll 1
+        for (int v = 0; v < n; v += 2) {
+            const Z4Tok c1 = mk(tok_of(v + 1)), c2 = mk(tok_of(v + 2));
             two_steps(c0, c1, c2);
             c0 = c2;
         }
+    };
+    auto masked_block = [&](int bi, int npos) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (int u0 = 0; u0 < npos; u0 += PER) masked_run(bi, u0, min(PER, npos - u0));
         zip3_rescale<NT>(P, ex);
     };
     if (maxlen > 0) masked_block(0, min(RESCALE_EVERY, (maxlen + 1) & ~1));
     if (nfull > 1) {
-        // full blocks: the 16 bytes of block bi + 1 are fetched while block bi runs, so the first token of the next
-        // block is known a step ahead and the cold-operand pipeline never drains inside this loop
-        uint4 ob = *reinterpret_cast<const uint4 *>(tokp + RESCALE_EVERY);
-        Z4Tok c0 = mk((int)(ob.x & 0xffu));
+        // full blocks: the tokens of block bi + 1 are fetched while block bi runs, so the first token of the next block
+        // is known a step ahead and the cold-operand pipeline never drains inside this loop.  The block's tokens sit
+        // in a shift register of 32-bit words: four tokens - one word of bytes, two words of 16-bit ids - per iteration.
+        constexpr int NW = 4 * TB;                                        // words per block
+        constexpr uint32_t TM = WIDE ? 0xffffu : 0xffu;
+        auto load_words = [&](int bi, uint32_t (&w)[NW]) __attribute__((always_inline)) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(tokp + (size_t)bi * RESCALE_EVERY * TB);
+            const uint4 x = src[0];
+            w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
+            if constexpr (WIDE) {
+                const uint4 y = src[1];
+                w[4] = y.x; w[5] = y.y; w[6] = y.z; w[7] = y.w;
+            }
+        };
+        uint32_t cw[NW];
+        load_words(1, cw);
+        Z4Tok c0 = mk((int)(cw[0] & TM));
         prime(c0);
         for (int bi = 1; bi < nfull; ++bi) {
-            uint4 nb = ob;
-            if (bi + 1 < nfull) nb = *reinterpret_cast<const uint4 *>(tokp + (size_t)(bi + 1) * RESCALE_EVERY);
-            uint32_t w0 = ob.x, w1 = ob.y, w2 = ob.z, w3 = ob.w;
+            const bool more = bi + 1 < nfull;
+            // the next block's first token now (one word), its other words once this block's have been consumed
+            const uint32_t nfirst = more ? *reinterpret_cast<const uint32_t *>(tokp + (size_t)(bi + 1) * RESCALE_EVERY * TB) : 0u;
 #pragma unroll 1
             for (int g4 = 0; g4 < 4; ++g4) {
-                const uint32_t w = w0;
-                w0 = w1; w1 = w2; w2 = w3; w3 = nb.x;
-                const Z4Tok c1 = mk((int)((w >> 8) & 0xffu)), c2 = mk((int)((w >> 16) & 0xffu));
-                two_steps(c0, c1, c2);
+                int t1, t2, t3, t4;
+                if constexpr (WIDE) {
+                    const uint32_t wa = cw[0], wb = cw[1];
+#pragma unroll
+                    for (int k = 0; k + 2 < NW; ++k) cw[k] = cw[k + 2];
+                    t1 = (int)(wa >> 16); t2 = (int)(wb & TM); t3 = (int)(wb >> 16);
+                } else {
+                    const uint32_t wa = cw[0];
+#pragma unroll
+                    for (int k = 0; k + 1 < NW; ++k) cw[k] = cw[k + 1];
+                    t1 = (int)((wa >> 8) & TM); t2 = (int)((wa >> 16) & TM); t3 = (int)(wa >> 24);
+                }
                 // (behind the last full block the pipeline is pointed at the identity: the block that follows, if any,
                 // is a masked one and primes itself)
-                const Z4Tok c3 = mk((int)(w >> 24)), c4 = mk((g4 == 3 && bi + 1 >= nfull) ? IDENT : (int)(w0 & 0xffu));
+                t4 = g4 < 3 ? (int)(cw[0] & TM) : more ? (int)(nfirst & TM) : IDENT;
+                if (g4 == 3 && more) load_words(bi + 1, cw);              // lands during the last four steps of this block
+                const Z4Tok c1 = mk(t1), c2 = mk(t2);
+                two_steps(c0, c1, c2);
+                const Z4Tok c3 = mk(t3), c4 = mk(t4);
                 two_steps(c2, c3, c4);
                 c0 = c4;
             }
             zip3_rescale<NT>(P, ex);
-            ob = nb;
         }
     }
     for (int bi = max(1, nfull); bi * RESCALE_EVERY < maxlen; ++bi)

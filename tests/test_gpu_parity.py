@@ -655,12 +655,27 @@ def test_hybrid_table_kernel(oracle, n, seg):
         set_zip(3)                                        # pinned: register-blocked kernel, fresh dictionary
         _capi.check(L.imc_set_blocked_kernel(5))          # hybrid table wherever a level beyond LDS exists
         fw = [Forwarder.from_array(c, 3) for c in chunks]
-        assert fw[0].compressed_length(256)[1] > 128      # the dictionary did grow
+        assert fw[0].compressed_length(256)[1] > 128      # the dictionary did grow (16-bit levels beyond 256 tokens too)
         set_seg(seg)
         got = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
         kernels = _capi.last_plan()["kernels"]
         if n > 8:                                         # (up to N = 8 every byte level fits LDS: plain k_zpropagate3)
             assert "k_zpropagate4" in kernels, kernels
+        # ... and pinned to every dictionary level up to 1024 tokens (byte streams to 256, 16-bit ids beyond)
+        seen = set()
+        for lvl in (7, 9, 10, 11, 12, 14):
+            os.environ["IMC_FORCE_LEVEL"] = str(lvl)
+            try:
+                forced = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+            finally:
+                del os.environ["IMC_FORCE_LEVEL"]
+            seen.add(_capi.last_plan()["kernels"])
+            for b in range(2):
+                for k in range(len(chunks)):
+                    w = want[b][k]
+                    assert (forced[b][k] == 0.0 and w == 0.0) or rel_err(forced[b][k], w) < TOL, (n, seg, lvl, b, k, _capi.last_plan())
+        if n > 8:
+            assert any(",16>" in k for k in seen), seen    # a 16-bit level ran on the hybrid kernel
         again = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
         assert np.array_equal(got, again)                 # bit-identical repeats
         _capi.check(L.imc_set_blocked_kernel(3))          # the LDS-table kernel on the same chunks agrees
