@@ -74,8 +74,13 @@ constexpr size_t DICT_TRAIN_MAX = 8u << 20;        // byte tokens (< 256): train
 constexpr size_t DICT_WIDE_TRAIN_TOKENS = 1u << 19; // 16-bit tokens: train on at most this many byte-level tokens (~4e7 columns)
 constexpr size_t DICT_WIDE_MIN_COUNT = 6;          // ... in which a pair must occur this often
 constexpr size_t CTAB_BUDGET = (size_t)24 << 30;   // largest operator table (all parameter sets) a plan may allocate
-constexpr int HYBRID_MAX_ALPHABET = 1024;          // hybrid table (k_zpropagate4): largest dictionary level considered (3.3 MB of
-                                                   // operators at N = 20: still resident in every XCD's 4 MB L2)
+#ifndef IMC_HYBRID_MAX_ALPHABET
+#define IMC_HYBRID_MAX_ALPHABET 4096
+#endif
+// hybrid table (k_zpropagate4): largest dictionary level considered.  Measured at N = 20 on the bench alignment: 1024 tokens
+// (3.3 MB of operators, resident in every XCD's 4 MB L2) 0.360 ms per evaluation, 1536: 0.347, 4096 (13 MB, Infinity
+// Cache): 0.342 - the columns per token saturate (133 / 139 / 150) while a cold step gets dearer
+constexpr int HYBRID_MAX_ALPHABET = IMC_HYBRID_MAX_ALPHABET;
 constexpr size_t Z2GRAN = 4;                       // blocked kernels: segment lengths are multiples of this many tokens
 constexpr size_t R1_MIN_SEGLEN = 1024;             // rank-one hand-off: segments at least this long (stream elements) ...
 constexpr size_t R1_MIN_HEAD = 256;                // ... run at least this many on the GEMM chain before the test
@@ -722,7 +727,9 @@ struct PlanBuilder {
                         if (!(A > o0->nsym && A <= HYBRID_MAX_ALPHABET && o0->d_tok[l]) || o0->wide_raw) continue;
                         const bool fits = !o0->wide[l] && kc->blocked_lds(A) <= LDS_BUDGET;   // (k_zpropagate3 reads byte streams)
                         const int max_hot = kc->zip4 ? kc->zip4_max_hot(A, LDS_BUDGET) : 0;
-                        const bool hybrid_ok = !fits && kc->zip4 && g.blocked_variant >= 4 && max_hot >= 8 && !o0->tok_count[l].empty();
+                        const double table_bytes = (double)B * (A + 1) * kc->tok_doubles * 8.0;
+                        const bool hybrid_ok = !fits && kc->zip4 && g.blocked_variant >= 4 && max_hot >= 8 && !o0->tok_count[l].empty() &&
+                                               table_bytes <= 2.0e9;
                         if (!fits && !hybrid_ok) continue;
                         double toks = 0.0;
                         for (int f : kv.second) toks += (double)chunks[f]->ntok[l];
@@ -746,7 +753,10 @@ struct PlanBuilder {
                             for (size_t z = 0; z < sorted.size(); ++z) { all += sorted[z]; if ((int)z < std::min(max_hot, A)) top += sorted[z]; }
                             const double cold = all ? 1.0 - (double)top / (double)all : 0.0;
                             const double depths = (double)std::max<int>(1, (int)std::set<int>(kv.first->depth.begin() + o0->nsym, kv.first->depth.begin() + A).size());
-                            cost = depths * 5.0 + 10.0 + steps * t_step * (1.0 + 0.12 * cold);   // one ~5 us launch per depth
+                            // one ~4 us launch per depth; a cold step costs ~11 % more while one parameter set's table
+                            // stays in an XCD's L2, ~17 % from the Infinity Cache (scratch microbenchmark)
+                            const double cold_pen = table_bytes / B <= 3.6e6 ? 0.11 : 0.17;
+                            cost = depths * 4.0 + 8.0 + steps * t_step * (1.0 + cold_pen * cold);
                         }
                         if (g.blocked_variant == 5 && !fits) cost *= 1e-3;      // tests: the hybrid table wherever it is possible
                         if (cost < best) { best = cost; best_l = l; }
