@@ -173,9 +173,12 @@ int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propag
 int imc_last_rank1(uint64_t *checked, uint64_t *collapsed);
 /* Switch the hand-off on (default) or off for plans built from now on (A/B comparisons, tests). */
 int imc_set_rank1_handoff(int on);
-/* Register-blocked kernel for N <= 24: 3 (default) = k_zpropagate3, the step issued as v_mfma_f64_4x4x4 (the DP units
- * are the same, the matrix form needs a quarter of the issue slots and no cross-lane moves); 2 = k_zpropagate2, the
- * VALU / DPP form (A/B measurements, tests).  IMC_BLOCKED=2 in the environment selects 2 at start-up. */
+/* Register-blocked kernel for N <= 24: 4 (default) = the fp64-MFMA scan (v_mfma_f64_4x4x4: the DP units are the same,
+ * the matrix form needs a quarter of the issue slots and no cross-lane moves) with its operator table in LDS
+ * (k_zpropagate3) or, where the planner's estimate says it pays, with a hybrid table - a dictionary level of up to
+ * 4096 tokens in global memory / L2, the hottest operators cached in LDS (k_zpropagate4); 3 = LDS table only;
+ * 5 = hybrid wherever a level beyond LDS exists (tests); 2 = k_zpropagate2, the VALU / DPP form (A/B measurements).
+ * IMC_BLOCKED=2..5 in the environment selects the variant at start-up. */
 int imc_set_blocked_kernel(int variant);
 /* Description of the last launch plan, out8[0..7] = segments, vectors, per-column segment length,
  * executed vector-columns (per-column kernel), token segment length, executed vector-tokens (token
