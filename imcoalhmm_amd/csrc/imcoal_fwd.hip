@@ -420,6 +420,7 @@ struct KernelChoice {
     size_t (*zip4_lds)(int, int) = nullptr;
     int (*zip4_max_hot)(int, size_t) = nullptr;
     int tok_doubles = 0;               // doubles per table entry of the MFMA kernels
+    bool chain_self_emax = false;      // the stitch kernel finds the units' largest exponents itself (no k_emax launch)
     bool zip4_attr_set = false, zip4w_attr_set = false;
     // the blocked kernel in use (g.blocked_variant) and its LDS need for an alphabet of A tokens
     bool use3() const;
@@ -432,6 +433,7 @@ KernelChoice make_kc()
     constexpr int NP = R * G;
     KernelChoice k{R, G, NP, 64 / G, MW, k_propagate<R, G, MW>, k_zpropagate<R, G>, &ZipGeom<R, G>::lds_bytes,
                    k_chain<NP, (NP <= 12 ? 6 : NP <= 24 ? 4 : NP <= 32 ? 3 : NP <= 64 ? 2 : 1)>, false, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, nullptr, nullptr, false};
+    k.chain_self_emax = true;          // (k_chain<NP, D > 0>: one wavefront, prefetch ring)
     if constexpr (NP % 4 == 0 && NP <= 24) {
         k.zip2 = k_zpropagate2<NP / 4>;
         k.zip2_lds = &Zip2Geom<NP / 4>::lds_bytes;
@@ -513,6 +515,7 @@ struct Group {             // one propagate launch
     uint16_t *d_hot = nullptr;
     uint16_t *d_tab_order = nullptr;          // blocked MFMA kernel: merged tokens of the alphabet by dictionary depth
     int *d_tab_lvl = nullptr;
+    int4 *d_tab_desc = nullptr;               // hybrid table: {token, left, right, 0} per entry of the depth order
     std::vector<int> tab_lvl;                 // host copy of the depth offsets
     int tab_nlvl = 0;
     double *d_Ctab = nullptr;
@@ -583,7 +586,7 @@ struct Plan {
         if (graph) (void)hipGraphExecDestroy(graph);
         dev_free(d_segs); dev_free(d_vecs); dev_free(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
+        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
         dev_free(d_params); dev_free(d_out);
         for (int k = 0; k < 2; ++k) { (void)hipHostFree(h_params[k]); if (ev_params[k]) (void)hipEventDestroy(ev_params[k]); }
         (void)hipHostFree(h_out);
@@ -1137,6 +1140,11 @@ struct PlanBuilder {
                 gr.tab_lvl = lvl;
                 e = up((void **)&gr.d_tab_order, order.data(), order.size() * sizeof(uint16_t));
                 if (e == hipSuccess) e = up((void **)&gr.d_tab_lvl, lvl.data(), lvl.size() * sizeof(int));
+                if (e == hipSuccess && gr.zip4) {
+                    std::vector<int4> desc;
+                    for (uint16_t z : order) desc.push_back(make_int4((int)z, (int)dd.dict.left[z], (int)dd.dict.right[z], 0));
+                    e = up((void **)&gr.d_tab_desc, desc.data(), desc.size() * sizeof(int4));
+                }
             }
             if (!gr.big || e != hipSuccess) continue;
             const size_t np2 = (size_t)kc->NP * kc->NP;
@@ -1342,7 +1350,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.phase = gr.rank1 ? 1 : 0; ba.t_from = 0; ba.t_to = gr.rank1 ? gr.checkpoints[0] : INT_MAX;
             ba.r1flag = gr.d_r1flag; ba.r1at = gr.d_r1at; ba.r1u = gr.d_r1u;
             ba.r1alpha = gr.d_r1alpha; ba.n_segs = p->n_segs;
-            ba.tab_order = nullptr; ba.tab_lvl = nullptr; ba.tab_nlvl = 0; ba.hot = nullptr; ba.n_hot = 0;
+            ba.tab_order = nullptr; ba.tab_lvl = nullptr; ba.tab_nlvl = 0; ba.hot = nullptr; ba.n_hot = 0; ba.tab_desc = nullptr;
             if (gr.rank1) HIP_TRY(hipMemsetAsync(gr.d_r1flag, 0, (size_t)B * p->n_segs * 4, stream));   // nothing certified yet
             hipLaunchKernelGGL(kc->big_table_raw, dim3((unsigned)S, (unsigned)B), dim3(kc->G * 64), 0, stream, ba);
             HIP_TRY(hipGetLastError());
@@ -1423,7 +1431,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.Ctab = nullptr; ba.cex = nullptr;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
             ba.tab_order = gr.d_tab_order; ba.tab_lvl = gr.d_tab_lvl; ba.tab_nlvl = gr.tab_nlvl;
-            ba.hot = gr.d_hot; ba.n_hot = gr.n_hot;
+            ba.hot = gr.d_hot; ba.n_hot = gr.n_hot; ba.tab_desc = gr.d_tab_desc;
             if (gr.zip4) {
                 // hybrid table: one workgroup per parameter set builds the operators in global memory (they stay in
                 // L2), then the scan caches the hot ones in LDS and streams the rest a step ahead
@@ -1492,9 +1500,11 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
     for (size_t l = 0; l + 1 < p->levels.size(); ++l) {
         const Level &in = p->levels[l], &ot = p->levels[l + 1];
         if (!in.n_segs || !ot.n_chains) continue;
-        hipLaunchKernelGGL(k_emax, dim3((in.n_segs + 255) / 256, (unsigned)B), dim3(256), 0, stream,
-                           in.d_vec0, in.d_first, in.n_segs, in.n_vecs, N, in.d_EX, in.d_EMAX);
-        HIP_TRY(hipGetLastError());
+        if (!kc->chain_self_emax) {   // (the single-wavefront chain kernels find the units' largest exponents themselves)
+            hipLaunchKernelGGL(k_emax, dim3((in.n_segs + 255) / 256, (unsigned)B), dim3(256), 0, stream,
+                               in.d_vec0, in.d_first, in.n_segs, in.n_vecs, N, in.d_EX, in.d_EMAX);
+            HIP_TRY(hipGetLastError());
+        }
         const int threads = (int)round_up((size_t)NP, 64);
         hipLaunchKernelGGL(kc->chain, dim3(ot.n_chains, (unsigned)B), dim3(threads), 0, stream,
                            ot.d_chains, N, in.d_vec0, in.n_segs, in.n_vecs, in.d_P, in.d_EX, in.d_EMAX,

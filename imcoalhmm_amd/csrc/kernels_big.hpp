@@ -58,6 +58,7 @@ struct BigArgs {
     // k_zpropagate4 (hybrid table): the n_hot most frequent tokens of the launch's chunks, cached in LDS (slot k = hot[k])
     const uint16_t *hot;
     int n_hot;
+    const int4 *tab_desc;         // k_z4_level: per entry of tab_order {token, left child, right child, 0} (one load instead of three dependent ones)
 };
 
 

@@ -36,7 +36,8 @@ __global__ void k_emax(const uint32_t *seg_vec0, const uint8_t *seg_first, uint3
 //     a <- Op_k * (a .* 2^(ex_k - emax_k))      for k in the run, rescaled by exact powers of two.
 // The operators of a run are consecutive N-vector blocks, so their addresses are known up front: the
 // rows and exponents of the next D operators are kept in flight in a register ring (D-deep prefetch),
-// which takes the L2/HBM latency (~0.7 us) off the serial chain.
+// which takes the L2/HBM latency (~0.7 us) off the serial chain.  With D > 0 (one wavefront, NP <= 64) the
+// kernel also finds each unit's largest exponent itself and EMin is not read.
 template <int NP, int D>
 __global__ __launch_bounds__(((NP + 63) / 64) * 64) void k_chain(
     const ChainDesc *chains, int N,
@@ -105,8 +106,11 @@ __global__ __launch_bounds__(((NP + 63) / 64) * 64) void k_chain(
     int exr[D > 0 ? D : 1], emr[D > 0 ? D : 1];
     auto fetch = [&](int t, int slot) {   // slot is a compile-time constant at every call site
         const size_t v0 = (size_t)vbase + (size_t)t * N;
-        emr[slot] = EMb[k0 + t];
-        exr[slot] = EXb[v0 + ii];
+        // the unit's largest column exponent, found here - D steps ahead of its use, off the serial chain - instead
+        // of by a k_emax launch per level (lanes beyond N repeat column 0, which is part of the maximum anyway)
+        const int exv = EXb[v0 + ii];
+        emr[slot] = wave_max_i32(exv);
+        exr[slot] = exv;
         const double2 *row = reinterpret_cast<const double2 *>(Pb + (v0 + ii) * NP);
 #pragma unroll
         for (int m = 0; m < NP / 2; ++m) pk[slot][m] = row[m];

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(64) void k_z4_level(BigArgs a, int first, int count
     int *Gc = a.cex + (size_t)b * (a.A + 1);
     const int ti = blockIdx.x * 4 + bq;
     const bool have = ti < count;
-    const int z = have ? (int)a.tab_order[first + ti] : a.A;          // (an idle block multiplies identities)
-    const int zl = have ? (int)a.tok_left[z] : a.A, zr = have ? (int)a.tok_right[z] : a.A;
+    const int4 td = have ? a.tab_desc[first + ti] : make_int4(a.A, a.A, a.A, 0);   // (an idle block multiplies identities)
+    const int z = td.x, zl = td.y, zr = td.z;
     const double *Gl = Gt + (size_t)zl * TOK, *Gr = Gt + (size_t)zr * TOK;
     double Bt[NT][NT], Ar[NT][NT], Out[NT][NT];
 #pragma unroll
