@@ -67,6 +67,10 @@ int fail(int code, const std::string &msg)
                         std::string(#expr) + ": " + hipGetErrorString(_e));                             \
     } while (0)
 
+// k_zpropagate4 caches nothing in LDS while the operator tables of one launch (all parameter sets) fit this many bytes -
+// they then stay in L2 / the Infinity Cache and a step's operands arrive from there a step ahead (IMC_Z4_STREAM=0/1
+// forces the hybrid / the streamed form)
+constexpr double Z4_STREAM_MAX_BYTES = 32.0e6;
 constexpr size_t LDS_BUDGET = 160 * 1024 - 1024;   // bytes of LDS a compressed-path workgroup may use
 constexpr size_t ZIP_MIN_COLUMNS = 4096;           // shorter chunks are not worth compressing
 constexpr size_t DICT_TRAIN_MIN = 32768;           // first chunk at least this long trains the dictionary
@@ -122,6 +126,8 @@ struct Ctx {
                               // (k_zpropagate4) and the LDS table otherwise (k_zpropagate3); 3 = LDS table only;
                               // 5 = hybrid wherever it is possible (tests); 2 = k_zpropagate2 (DPP, VALU).
                               // IMC_BLOCKED=2|3|4|5 at start-up
+    int z4_stream = -1;       // k_zpropagate4's table: -1 = streamed (nothing cached in LDS) while the launch's tables are
+                              // cache resident, 0 = always the hybrid LDS cache, 1 = always streamed (IMC_Z4_STREAM)
     bool guard = false;       // IMC_GUARD=1: every device buffer ends flush against an unmapped guard range (dev_alloc)
     bool use_graphs = false;  // IMC_GRAPH=1: replay each plan's launch sequence as a hipGraph (measured: no gain, the
                               // per-evaluation latency is kernel time + kernel boundaries, not host launch cost)
@@ -166,6 +172,7 @@ int ensure_ctx()
     if (const char *gd = std::getenv("IMC_GUARD")) g.guard = std::atoi(gd) != 0;
     if (const char *bv = std::getenv("IMC_BLOCKED")) { const int v = std::atoi(bv); if (v >= 2 && v <= 5) g.blocked_variant = v; }
     if (const char *r1 = std::getenv("IMC_RANK1")) g.rank1_handoff = std::atoi(r1) != 0;
+    if (const char *zs = std::getenv("IMC_Z4_STREAM")) { const int v = std::atoi(zs); if (v >= -1 && v <= 1) g.z4_stream = v; }
     g.pid = me;
     g.ready = true;
     return IMC_OK;
@@ -415,13 +422,14 @@ struct KernelChoice {
     bool zip3_attr_set = false;
     void (*zip4)(BigArgs) = nullptr;   // ... with the hybrid LDS / L2 operator table, and the kernels that build that table
     void (*zip4w)(BigArgs) = nullptr;  // ... on 16-bit token streams (dictionary levels beyond 256 tokens)
+    void (*zip4s)(BigArgs) = nullptr, (*zip4sw)(BigArgs) = nullptr;   // ... with the STREAMED table (nothing cached in LDS)
     void (*zip4_raw)(BigArgs) = nullptr;
     void (*zip4_level)(BigArgs, int, int) = nullptr;
     size_t (*zip4_lds)(int, int) = nullptr;
     int (*zip4_max_hot)(int, size_t) = nullptr;
     int tok_doubles = 0;               // doubles per table entry of the MFMA kernels
     bool chain_self_emax = false;      // the stitch kernel finds the units' largest exponents itself (no k_emax launch)
-    bool zip4_attr_set = false, zip4w_attr_set = false;
+    bool zip4_attr_set = false, zip4w_attr_set = false, zip4s_attr_set = false, zip4sw_attr_set = false;
     // the blocked kernel in use (g.blocked_variant) and its LDS need for an alphabet of A tokens
     bool use3() const;
     size_t blocked_lds(int A) const { return use3() ? zip3_lds(A) : zip2_lds(A); }
@@ -441,8 +449,10 @@ KernelChoice make_kc()
         k.zip3_lds = &Zip3Geom<NP / 4>::lds_bytes;
         k.tok_doubles = Zip3Geom<NP / 4>::TOK;
         if constexpr (NP <= 20) {   // (NP = 24: the extra 36 operand registers of the hybrid form would spill)
-            k.zip4 = k_zpropagate4<NP / 4, false>;
-            k.zip4w = k_zpropagate4<NP / 4, true>;
+            k.zip4 = k_zpropagate4<NP / 4, false, true>;
+            k.zip4w = k_zpropagate4<NP / 4, true, true>;
+            k.zip4s = k_zpropagate4<NP / 4, false, false>;
+            k.zip4sw = k_zpropagate4<NP / 4, true, false>;
             k.zip4_raw = k_z4_raw<NP / 4>;
             k.zip4_level = k_z4_level<NP / 4>;
             k.zip4_lds = &Zip4Geom<NP / 4>::lds_bytes;
@@ -492,8 +502,8 @@ KernelChoice *choose_kernel(int N, bool prefer_gemm)
 
 void reset_kernel_attributes()
 {
-    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.zip4w_attr_set = k.plain_attr_set = false;
-    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.zip4w_attr_set = k.plain_attr_set = false;
+    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.zip4w_attr_set = k.zip4s_attr_set = k.zip4sw_attr_set = k.plain_attr_set = false;
+    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.zip4w_attr_set = k.zip4s_attr_set = k.zip4sw_attr_set = k.plain_attr_set = false;
 }
 
 // ---- launch plan ----------------------------------------------------------------------------------
@@ -510,6 +520,7 @@ struct Group {             // one propagate launch
     Z2Block *d_blocks = nullptr;
     bool zip4 = false;                        // blocked MFMA kernel with the hybrid table: alphabet beyond LDS, n_hot operators cached
     bool wide_tokens = false;                 // ... its token stream holds 16-bit ids
+    bool stream_table = false;                // ... nothing cached in LDS: the launch's tables are small enough to stay cache resident
     int n_hot = 0;
     std::vector<uint16_t> hot;
     uint16_t *d_hot = nullptr;
@@ -1115,7 +1126,9 @@ struct PlanBuilder {
                 std::vector<uint16_t> ids((size_t)gr.A);
                 for (int z = 0; z < gr.A; ++z) ids[z] = (uint16_t)z;
                 std::stable_sort(ids.begin(), ids.end(), [&](uint16_t x, uint16_t y) { return cnt[x] > cnt[y]; });
-                gr.n_hot = std::min(gr.A, kc->zip4_max_hot(gr.A, LDS_BUDGET));
+                const double tables = (double)B * (gr.A + 1) * kc->tok_doubles * 8.0;
+                gr.stream_table = g.z4_stream == 1 || (g.z4_stream < 0 && tables <= Z4_STREAM_MAX_BYTES);
+                gr.n_hot = gr.stream_table ? 0 : std::min(gr.A, kc->zip4_max_hot(gr.A, LDS_BUDGET));
                 gr.hot.assign(ids.begin(), ids.begin() + gr.n_hot);
                 e = up((void **)&gr.d_hot, gr.hot.data(), gr.hot.size() * sizeof(uint16_t));
                 if (e == hipSuccess) e = dev_alloc((void **)&gr.d_Ctab, (size_t)B * (gr.A + 1) * kc->tok_doubles * 8);
@@ -1210,7 +1223,7 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
     key.reserve(n_chunks + 5);
     for (int f = 0; f < n_chunks; ++f) key.push_back(chunks[f]->id);
     key.push_back((uint64_t)N); key.push_back((uint64_t)S); key.push_back((uint64_t)B);
-    key.push_back((uint64_t)g.seg_override); key.push_back((uint64_t)(g.compression * 4 + g.kernel_pref + (op_mode ? 64 : 0) + g.blocked_variant * 128));
+    key.push_back((uint64_t)g.seg_override); key.push_back((uint64_t)(g.compression * 4 + g.kernel_pref + (op_mode ? 64 : 0) + g.blocked_variant * 128 + (g.z4_stream + 1) * 1024));
     { const char *fl = std::getenv("IMC_FORCE_LEVEL"); key.push_back(fl ? (uint64_t)(std::atoi(fl) + 1) : 0u); }   // (experiments / tests)
     for (auto it = g_plans.begin(); it != g_plans.end(); ++it) {
         if ((*it)->key == key) {
@@ -1443,15 +1456,16 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                     hipLaunchKernelGGL(kc->zip4_level, dim3((unsigned)(count + 3) / 4, (unsigned)B), dim3(64), 0, stream, ba, first, count);
                     HIP_TRY(hipGetLastError());
                 }
-                void (*scan)(BigArgs) = gr.wide_tokens ? kc->zip4w : kc->zip4;
-                bool &attr4 = gr.wide_tokens ? kc->zip4w_attr_set : kc->zip4_attr_set;
+                void (*scan)(BigArgs) = gr.stream_table ? (gr.wide_tokens ? kc->zip4sw : kc->zip4s) : (gr.wide_tokens ? kc->zip4w : kc->zip4);
+                bool &attr4 = gr.stream_table ? (gr.wide_tokens ? kc->zip4sw_attr_set : kc->zip4s_attr_set)
+                                              : (gr.wide_tokens ? kc->zip4w_attr_set : kc->zip4_attr_set);
                 if (!attr4) {
                     HIP_TRY(hipFuncSetAttribute((const void *)scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
                     attr4 = true;
                 }
                 hipLaunchKernelGGL(scan, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64),
                                    kc->zip4_lds(gr.A, gr.n_hot), stream, ba);
-                note(std::string("k_zpropagate4<") + std::to_string(NP / 4) + (gr.wide_tokens ? ",16>" : ">") + strm);
+                note(std::string("k_zpropagate4<") + std::to_string(NP / 4) + (gr.wide_tokens ? ",16" : "") + (gr.stream_table ? ",streamed>" : ">") + strm);
                 lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A);
                 HIP_TRY(hipGetLastError());
                 continue;
@@ -1539,6 +1553,17 @@ void collect_rank1_stats(Plan *p)
                 ++g.r1_checked;
                 g.r1_collapsed += flags[(size_t)b * p->n_segs + sl.first] ? 1 : 0;
             }
+        if (getenv("IMC_DEBUG_R1")) {          // where each head was certified (diagnostics only)
+            std::vector<int> at((size_t)p->B * p->n_segs);
+            if (hipMemcpy(at.data(), gr.d_r1at, at.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) continue;
+            std::map<int, int> hist;
+            for (const auto &sl : gr.r1_segs) hist[flags[sl.first] ? at[sl.first] : -1]++;
+            fprintf(stderr, "[imc] rank-one hand-off: segment length %zu tokens, checkpoints", (size_t)gr.seglen);
+            for (int c : gr.checkpoints) fprintf(stderr, " %d", c);
+            fprintf(stderr, "\n[imc]   certified at (tokens: segments)");
+            for (auto &kv : hist) fprintf(stderr, " %d:%d", kv.first, kv.second);
+            fprintf(stderr, "\n");
+        }
     }
 }
 
@@ -1925,11 +1950,27 @@ int imc_set_rank1_handoff(int on)
     return IMC_OK;
 }
 
+#ifdef IMC_Z4_TIMING
+int imc_debug_z4_timing(long long *out, int n)     // diagnostics build only (see kernels_zip4.hpp)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_z4_dbg), (size_t)std::min(n, 3 * 1024 * 8) * 8) != hipSuccess) return IMC_ERR_HIP;
+    return IMC_OK;
+}
+#endif
+
 int imc_set_blocked_kernel(int variant)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     if (variant < 2 || variant > 5) return fail(IMC_ERR_ARG, "blocked kernel variant must be 2 (VALU/DPP), 3 (fp64 MFMA, LDS table), 4 (+ hybrid table, default) or 5 (hybrid wherever possible)");
     g.blocked_variant = variant;            // (part of the plan key: cached plans of the other variant stay valid)
+    return IMC_OK;
+}
+
+int imc_set_table_streaming(int mode)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (mode < -1 || mode > 1) return fail(IMC_ERR_ARG, "table streaming mode must be -1 (automatic), 0 (hybrid LDS cache) or 1 (streamed)");
+    g.z4_stream = mode;                     // (part of the plan key)
     return IMC_OK;
 }
 

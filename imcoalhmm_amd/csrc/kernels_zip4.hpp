@@ -132,20 +132,28 @@ struct Z4Tok {              // one step's operator for this lane's segment (kept
 // Pout <- C_cur * Pin.  `al` holds tile-row 0 of cur's LDS entry on entry and of nxt's on exit (as zip3_step);
 // `pre` holds ALL tile-rows of cur's global entry if cur is cold, and is refilled tile-row by tile-row with nxt's
 // entry (if that is cold) as soon as each row has been consumed.
-template <int NT>
-__device__ __forceinline__ void zip4_step(const double (&Pin)[NT][NT], double (&Pout)[NT][NT], const double *C, const double *Gt,
+template <int NT, bool HYB>
+__device__ __forceinline__ void zip4_step(const double (&Pin)[NT][NT], double (&Pout)[NT][NT], const double *C, const double *Gt, const double *Gi,
                                           const Z4Tok &cur, const Z4Tok &nxt, double (&al)[NT], double (&pre)[NT][NT], int lo, int lx)
 {
     constexpr int TOK = Zip3Geom<NT>::TOK;
+    // The refill is issued for EVERY step - a hot next token fetches the identity entry `Gi` instead (the same few
+    // cache lines for every such lane: L1 hits) - so that the number of loads in flight is the same on every path and
+    // the compiler can wait for exactly the tile-row it needs (with the loads under a branch it waited for all of
+    // them, vmcnt(0), at the top of every step: the L2 round trip of the last tile-row, issued 25 MFMAs earlier, was
+    // exposed on every cold step).
+    // HYB = false (streamed table): no LDS copies at all - every operand comes from `pre`.
+    const bool cur_cold = !HYB || cur.s < 0, nxt_cold = !HYB || nxt.s < 0;
+    const double *Gn = nxt_cold ? Gt + (size_t)nxt.tok * TOK : Gi;
     // (a cold token reads LDS slot 0: a valid address whose data is not used)
     const double *Cz = C + (size_t)max(cur.s, 0) * TOK, *Cn = C + (size_t)max(nxt.s, 0) * TOK;
-    const double *Gn = Gt + (size_t)nxt.tok * TOK;
-    const bool cur_cold = cur.s < 0, nxt_cold = nxt.s < 0;
 #pragma unroll
     for (int I = 0; I < NT; ++I) {
         double an[NT], av[NT];
-        if (I + 1 < NT) zip3_load_row<NT>(an, Cz, I + 1, lo, lx);
-        else zip3_load_row<NT>(an, Cn, 0, lo, lx);
+        if constexpr (HYB) {
+            if (I + 1 < NT) zip3_load_row<NT>(an, Cz, I + 1, lo, lx);
+            else zip3_load_row<NT>(an, Cn, 0, lo, lx);
+        }
 #pragma unroll
         for (int K = 0; K < NT; ++K) av[K] = cur_cold ? pre[I][K] : al[K];
         __builtin_amdgcn_sched_barrier(0);         // keep the LDS prefetch ahead of this tile-row's MFMAs
@@ -155,14 +163,26 @@ __device__ __forceinline__ void zip4_step(const double (&Pin)[NT][NT], double (&
             for (int J = 0; J < NT; ++J)
                 Pout[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[K], Pin[K][J], K == 0 ? 0.0 : Pout[I][J], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        if (nxt_cold) zip4_load_row_global<NT>(pre[I], Gn, I, lo, lx);   // (per lane; a full step ahead of its use)
+        zip4_load_row_global<NT>(pre[I], Gn, I, lo, lx);                 // (per lane; a full step ahead of its use)
+        if constexpr (HYB) {
 #pragma unroll
-        for (int K = 0; K < NT; ++K) al[K] = an[K];
+            for (int K = 0; K < NT; ++K) al[K] = an[K];
+        }
     }
 }
 
+#ifdef IMC_Z4_TIMING      // diagnostics build only: phase timestamps (100 MHz clock) of wavefront 0 of every workgroup
+__device__ long long g_z4_dbg[1024 * 8 * 3];        // [0]: phases of wavefront 0; [1]: scan end per wavefront; [2]: fold levels
+#define Z4_STAMP(k_) do { if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0) g_z4_dbg[blockIdx.x * 8 + (k_)] = wall_clock64(); } while (0)
+#else
+#define Z4_STAMP(k_) do { } while (0)
+#endif
+
 // WIDE: the token stream holds 16-bit ids (dictionary levels beyond 256 tokens) instead of bytes.
-template <int NT, bool WIDE>
+// HYB = false: the STREAMED table - nothing is cached in LDS, every step's operands arrive from the global table
+// (L1 / L2 / Infinity Cache) a step ahead.  Without the per-row LDS reads and the LDS-or-register selects a step is
+// ~10 % faster as long as the tables of a launch stay cache resident (the host decides: Z4_STREAM_MAX_BYTES).
+template <int NT, bool WIDE, bool HYB>
 __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigArgs a)
 {
     constexpr int TB = WIDE ? 2 : 1;                                   // bytes per token
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     using G4 = Zip4Geom<NT>;
     constexpr int NP = Geo::NP, TOK = Geo::TOK, THREADS = Z2WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int H = a.n_hot;                                             // hot operators; LDS slot H = the identity
+    const int H = HYB ? a.n_hot : 0;                                   // hot operators; LDS slot H = the identity
     double *C = lds;                                                   // [slots(H)][TOK]
     int *cex = reinterpret_cast<int *>(C + (size_t)G4::slots(H) * TOK);   // [A + 1] exponents of the table entries
     int *slot_of = cex + a.A + 2;                                      // [A + 1] LDS slot of a token, -1 = cold
@@ -184,19 +204,24 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     const double *Gt = a.Ctab + (size_t)b * (a.A + 1) * TOK;
     const int *Gc = a.cex + (size_t)b * (a.A + 1);
     const int IDENT = a.A;
+    const double *Gi = Gt + (size_t)IDENT * TOK;
 
     // ---- LDS: exponents, slot map, the hot operators and the identity ----
+    Z4_STAMP(0);
     for (int z = tid; z <= a.A; z += THREADS) { cex[z] = Gc[z]; slot_of[z] = -1; }
-    __syncthreads();
-    for (int k = tid; k <= H; k += THREADS) slot_of[k < H ? (int)a.hot[k] : IDENT] = k;
-    for (int idx = tid; idx < (H + 1) * (TOK / 2); idx += THREADS) {
-        const int k = idx / (TOK / 2), w = idx - k * (TOK / 2);
-        const int z = k < H ? (int)a.hot[k] : IDENT;
-        reinterpret_cast<double2 *>(C + (size_t)k * TOK)[w] = reinterpret_cast<const double2 *>(Gt + (size_t)z * TOK)[w];
+    if constexpr (HYB) {
+        __syncthreads();
+        for (int k = tid; k <= H; k += THREADS) slot_of[k < H ? (int)a.hot[k] : IDENT] = k;
+        for (int idx = tid; idx < (H + 1) * (TOK / 2); idx += THREADS) {
+            const int k = idx / (TOK / 2), w = idx - k * (TOK / 2);
+            const int z = k < H ? (int)a.hot[k] : IDENT;
+            reinterpret_cast<double2 *>(C + (size_t)k * TOK)[w] = reinterpret_cast<const double2 *>(Gt + (size_t)z * TOK)[w];
+        }
     }
     __syncthreads();
 
     // ---- scan: one segment per MFMA block ----
+    Z4_STAMP(1);
     const int lane = tid & 63;
     const int q = lane >> 4, bq = (lane >> 2) & 3, r = lane & 3;
     const int lo = (q * 4 + r) * Geo::NTE, lx = q * 4 + r;
@@ -208,6 +233,14 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     const int len = valid ? (int)sd.len : 0;
     const bool first = (sd.first & SEG_FIRST) != 0;
     const uint8_t *tokp = sd.obs;
+    // (token loads as GLOBAL loads: through the generic pointer of the segment descriptor they are flat loads, which
+    // count against the LDS counter too and can return out of order with the operand refills - every wait behind one
+    // becomes a full one)
+    typedef const __attribute__((address_space(1))) uint8_t *gptr;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4 *gptr4;
+    typedef const __attribute__((address_space(1))) uint32_t *gptr1;
+    const gptr tokg = (gptr)tokp;
 
     double P[NT][NT], Q[NT][NT];
     {
@@ -227,14 +260,14 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     const int maxlen = wave_max_i32(len);
     const int nfull = maxlen == 0 ? 0 : wave_min_i32(valid ? len / RESCALE_EVERY : INT_MAX);   // idle wavefronts still join the fold's barriers
 
-    double al[NT], pre[NT][NT];
+    double al[NT] = {}, pre[NT][NT];
 #pragma unroll
     for (int I = 0; I < NT; ++I)
 #pragma unroll
         for (int K = 0; K < NT; ++K) pre[I][K] = 0.0;
     auto mk = [&](int tok) __attribute__((always_inline)) {
         Z4Tok t;
-        t.s = slot_of[tok];
+        t.s = HYB ? slot_of[tok] : -1;
         t.ce = cex[tok];
         t.tok = tok;
         return t;
@@ -242,16 +275,14 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     // start (or restart) the pipeline at `c`: its LDS row 0 and, if it is cold, all of its global rows - exposed latency,
     // paid at the start of a segment and where the token of the next position is not known a step ahead
     auto prime = [&](const Z4Tok &c) __attribute__((always_inline)) {
-        zip3_load_row<NT>(al, C + (size_t)max(c.s, 0) * TOK, 0, lo, lx);
-        if (c.s < 0) {
-            const double *Gc0 = Gt + (size_t)c.tok * TOK;
+        if constexpr (HYB) zip3_load_row<NT>(al, C + (size_t)max(c.s, 0) * TOK, 0, lo, lx);
+        const double *Gc0 = c.s < 0 ? Gt + (size_t)c.tok * TOK : Gi;        // (unconditional, as zip4_step's refill)
 #pragma unroll
-            for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(pre[I], Gc0, I, lo, lx);
-        }
+        for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(pre[I], Gc0, I, lo, lx);
     };
     auto two_steps = [&](const Z4Tok &t0, const Z4Tok &t1, const Z4Tok &tn) __attribute__((always_inline)) {
-        zip4_step<NT>(P, Q, C, Gt, t0, t1, al, pre, lo, lx);
-        zip4_step<NT>(Q, P, C, Gt, t1, tn, al, pre, lo, lx);
+        zip4_step<NT, HYB>(P, Q, C, Gt, Gi, t0, t1, al, pre, lo, lx);
+        zip4_step<NT, HYB>(Q, P, C, Gt, Gi, t1, tn, al, pre, lo, lx);
         ex += t0.ce + t1.ce;
     };
     // A block of 16 positions in which not every lane's segment has a token (see k_zpropagate3): per run of PER positions
@@ -260,7 +291,10 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     constexpr int PER = WIDE ? 8 : 16;
     auto masked_run = [&](int bi, int u0, int n) __attribute__((always_inline)) {   // positions u0 .. u0 + n - 1 of block bi, n even
         uint4 ob = make_uint4(0u, 0u, 0u, 0u);
-        if (bi * RESCALE_EVERY + u0 < len) ob = *reinterpret_cast<const uint4 *>(tokp + ((size_t)bi * RESCALE_EVERY + u0) * TB);
+        if (bi * RESCALE_EVERY + u0 < len) {
+            const u32x4 v = *(gptr4)(tokg + ((size_t)bi * RESCALE_EVERY + u0) * TB);
+            ob = make_uint4(v.x, v.y, v.z, v.w);
+        }
         const int live = len - bi * RESCALE_EVERY - u0;                 // run positions v < live hold a token
         const int dead0 = (first && bi == 0 && u0 == 0) ? 0 : -1;
         const unsigned long long lo64 = (unsigned long long)ob.y << 32 | ob.x, hi64 = (unsigned long long)ob.w << 32 | ob.z;
@@ -284,6 +318,7 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
         zip3_rescale<NT>(P, ex);
     };
     if (maxlen > 0) masked_block(0, min(RESCALE_EVERY, (maxlen + 1) & ~1));
+    Z4_STAMP(2);
     if (nfull > 1) {
         // full blocks: the tokens of block bi + 1 are fetched while block bi runs, so the first token of the next block
         // is known a step ahead and the cold-operand pipeline never drains inside this loop.  The block's tokens sit
@@ -291,11 +326,11 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
         constexpr int NW = 4 * TB;                                        // words per block
         constexpr uint32_t TM = WIDE ? 0xffffu : 0xffu;
         auto load_words = [&](int bi, uint32_t (&w)[NW]) __attribute__((always_inline)) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(tokp + (size_t)bi * RESCALE_EVERY * TB);
-            const uint4 x = src[0];
+            gptr4 src = (gptr4)(tokg + (size_t)bi * RESCALE_EVERY * TB);
+            const u32x4 x = src[0];
             w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
             if constexpr (WIDE) {
-                const uint4 y = src[1];
+                const u32x4 y = src[1];
                 w[4] = y.x; w[5] = y.y; w[6] = y.z; w[7] = y.w;
             }
         };
@@ -304,10 +339,14 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
         Z4Tok c0 = mk((int)(cw[0] & TM));
         prime(c0);
         for (int bi = 1; bi < nfull; ++bi) {
+            // Straight-line body (no load under a branch: the compiler then waits for exactly the loads it needs): the
+            // next block's first token now (one word), its other words once this block's have been consumed; behind
+            // the last full block both re-read the current block and the pipeline is pointed at the identity (the
+            // block that follows, if any, is a masked one and primes itself).
             const bool more = bi + 1 < nfull;
-            // the next block's first token now (one word), its other words once this block's have been consumed
-            const uint32_t nfirst = more ? *reinterpret_cast<const uint32_t *>(tokp + (size_t)(bi + 1) * RESCALE_EVERY * TB) : 0u;
-#pragma unroll 1
+            const int bn = more ? bi + 1 : bi;
+            const uint32_t nfirst = *(gptr1)(tokg + (size_t)bn * RESCALE_EVERY * TB);
+#pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 int t1, t2, t3, t4;
                 if constexpr (WIDE) {
@@ -321,10 +360,8 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
                     for (int k = 0; k + 1 < NW; ++k) cw[k] = cw[k + 1];
                     t1 = (int)((wa >> 8) & TM); t2 = (int)((wa >> 16) & TM); t3 = (int)(wa >> 24);
                 }
-                // (behind the last full block the pipeline is pointed at the identity: the block that follows, if any,
-                // is a masked one and primes itself)
                 t4 = g4 < 3 ? (int)(cw[0] & TM) : more ? (int)(nfirst & TM) : IDENT;
-                if (g4 == 3 && more) load_words(bi + 1, cw);              // lands during the last four steps of this block
+                if (g4 == 3) load_words(bn, cw);                          // lands during the last four steps of this block
                 const Z4Tok c1 = mk(t1), c2 = mk(t2);
                 two_steps(c0, c1, c2);
                 const Z4Tok c3 = mk(t3), c4 = mk(t4);
@@ -334,9 +371,14 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
             zip3_rescale<NT>(P, ex);
         }
     }
+    Z4_STAMP(3);
     for (int bi = max(1, nfull); bi * RESCALE_EVERY < maxlen; ++bi)
         masked_block(bi, min(RESCALE_EVERY, (maxlen - bi * RESCALE_EVERY + 1) & ~1));
     zip3_rescale<NT>(P, ex);
+    Z4_STAMP(4);
+#ifdef IMC_Z4_TIMING
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024 && blockIdx.y == 0) g_z4_dbg[1024 * 8 + blockIdx.x * 8 + (threadIdx.x >> 6)] = wall_clock64();
+#endif
 
     // ---- fold the workgroup's segments into one (k_zpropagate3's fold: LDS entries become the exchange area) ----
     for (int stride = 1; stride < Z2SLOTS; stride <<= 1) {
@@ -368,8 +410,15 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
 #pragma unroll
             for (int J = 0; J < NT; ++J) P[K][J] = Q[K][J];
         zip3_rescale<NT>(P, ex);
+#ifdef IMC_Z4_TIMING
+        if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0) g_z4_dbg[2 * 1024 * 8 + blockIdx.x * 8 + (31 - __clz(stride))] = wall_clock64();
+#endif
     }
 
+    Z4_STAMP(5);
+#ifdef IMC_Z4_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0) g_z4_dbg[blockIdx.x * 8 + 7] = (long long)nfull * 1000000 + maxlen;
+#endif
     if (slot == 0) {
         const size_t gv = (size_t)b * a.n_vecs_total + blk.out_vec0;
         double *Pout = a.P + gv * NP;

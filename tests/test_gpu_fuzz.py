@@ -38,8 +38,10 @@ def test_random_dispatch(oracle, case):
     hmms = [synth.random_hmm(n, nsym, seed=case * 10 + b, stay=float(rng.choice([0.5, 0.9, 0.999]))) for b in range(B)]
     chunks = [_chunk(rng, nsym, x) for x in lens]
     variant = int(rng.choice([2, 3, 4, 5, 5]))           # form of the register-blocked kernel (N <= 24): VALU, MFMA + LDS table,
+    stream = int(rng.choice([-1, 0, 1]))                 # k_zpropagate4's table: automatic, LDS-cached hot set, streamed
     try:                                                 # automatic, hybrid table wherever possible
         _capi.check(L.imc_set_blocked_kernel(variant))
+        _capi.check(L.imc_set_table_streaming(stream))
         _capi.check(L.imc_set_compression(mode))
         _capi.check(L.imc_dictionary_reset())
         _capi.check(L.imc_set_segment_length(seg))
@@ -49,13 +51,14 @@ def test_random_dispatch(oracle, case):
         kernels = _capi.last_plan()["kernels"]
     finally:
         L.imc_set_blocked_kernel(4)
+        L.imc_set_table_streaming(-1)
         L.imc_set_compression(1)
         L.imc_set_segment_length(0)
     for b in range(B):
         for f, c in enumerate(chunks):
             want = oracle.forward_scaled(*hmms[b], c)
             g = got[b, f]
-            assert (g == 0.0 and want == 0.0) or rel_err(g, want) < 1e-11, (case, n, nsym, mode, variant, seg, B, lens, kernels, b, f, g, want)
+            assert (g == 0.0 and want == 0.0) or rel_err(g, want) < 1e-11, (case, n, nsym, mode, variant, stream, seg, B, lens, kernels, b, f, g, want)
 
 
 @pytest.mark.parametrize("case", range(max(40, N_CASES // 4)))

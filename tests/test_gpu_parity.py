@@ -641,11 +641,13 @@ def test_forwarder_attributes_of_the_reference(example_pairs):
 
 @pytest.mark.parametrize("n", [4, 8, 10, 13, 16, 20])
 @pytest.mark.parametrize("seg", [0, 52, 1000])
-def test_hybrid_table_kernel(oracle, n, seg):
-    """k_zpropagate4: a dictionary level far beyond what LDS holds (up to 256 tokens), operators in a global table, the
-    hottest cached in LDS, the others streamed a step ahead.  Long compressible chunks so that the dictionary grows
-    past LDS; ragged / tiny / empty chunks ride along; two parameter sets; forced segment lengths that are not
-    multiples of 16 (the masked first / last blocks) and 4-token granularity."""
+@pytest.mark.parametrize("stream", [0, 1])
+def test_hybrid_table_kernel(oracle, n, seg, stream):
+    """k_zpropagate4: a dictionary level far beyond what LDS holds (up to 4096 tokens), operators in a global table -
+    stream = 0: the hottest cached in LDS, the others streamed a step ahead; stream = 1: every operator streamed.
+    Long compressible chunks so that the dictionary grows past LDS; ragged / tiny / empty chunks ride along; two
+    parameter sets; forced segment lengths that are not multiples of 16 (the masked first / last blocks) and
+    4-token granularity."""
     L = _capi.lib()
     hmms = [synth.random_hmm(n, 3, seed=4000 + n + b, stay=0.995) for b in range(2)]
     pis, Ts, Es = (np.stack([h[k] for h in hmms]) for k in range(3))
@@ -654,13 +656,14 @@ def test_hybrid_table_kernel(oracle, n, seg):
     try:
         set_zip(3)                                        # pinned: register-blocked kernel, fresh dictionary
         _capi.check(L.imc_set_blocked_kernel(5))          # hybrid table wherever a level beyond LDS exists
+        _capi.check(L.imc_set_table_streaming(stream))
         fw = [Forwarder.from_array(c, 3) for c in chunks]
         assert fw[0].compressed_length(256)[1] > 128      # the dictionary did grow (16-bit levels beyond 256 tokens too)
         set_seg(seg)
         got = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
         kernels = _capi.last_plan()["kernels"]
         if n > 8:                                         # (up to N = 8 every byte level fits LDS: plain k_zpropagate3)
-            assert "k_zpropagate4" in kernels, kernels
+            assert "k_zpropagate4" in kernels and ("streamed" in kernels) == bool(stream), kernels
         # ... and pinned to every dictionary level up to 1024 tokens (byte streams to 256, 16-bit ids beyond)
         seen = set()
         for lvl in (7, 9, 10, 11, 12, 14):
@@ -675,7 +678,7 @@ def test_hybrid_table_kernel(oracle, n, seg):
                     w = want[b][k]
                     assert (forced[b][k] == 0.0 and w == 0.0) or rel_err(forced[b][k], w) < TOL, (n, seg, lvl, b, k, _capi.last_plan())
         if n > 8:
-            assert any(",16>" in k for k in seen), seen    # a 16-bit level ran on the hybrid kernel
+            assert any(",16" in k for k in seen), seen     # a 16-bit level ran on the hybrid kernel
         again = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
         assert np.array_equal(got, again)                 # bit-identical repeats
         _capi.check(L.imc_set_blocked_kernel(3))          # the LDS-table kernel on the same chunks agrees
@@ -684,6 +687,7 @@ def test_hybrid_table_kernel(oracle, n, seg):
     finally:
         set_seg(0)
         _capi.check(L.imc_set_blocked_kernel(4))
+        _capi.check(L.imc_set_table_streaming(-1))
         set_zip(1)
     for b in range(2):
         for k in range(len(chunks)):
