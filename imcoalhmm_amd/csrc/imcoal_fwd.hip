@@ -28,6 +28,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <list>
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <set>
 #include <memory>
@@ -71,6 +73,7 @@ int fail(int code, const std::string &msg)
 // they then stay in L2 / the Infinity Cache and a step's operands arrive from there a step ahead (IMC_Z4_STREAM=0/1
 // forces the hybrid / the streamed form)
 constexpr double Z4_STREAM_MAX_BYTES = 32.0e6;
+constexpr size_t STAGE_KERNEL_MAX_BYTES = 1u << 20;   // parameter sets up to this size are fetched by k_stage_params (enqueue)
 constexpr size_t LDS_BUDGET = 160 * 1024 - 1024;   // bytes of LDS a compressed-path workgroup may use
 constexpr size_t ZIP_MIN_COLUMNS = 4096;           // shorter chunks are not worth compressing
 constexpr size_t DICT_TRAIN_MIN = 32768;           // first chunk at least this long trains the dictionary
@@ -586,8 +589,15 @@ struct Plan {
     hipEvent_t ev_params[2] = {nullptr, nullptr};
     bool ev_used[2] = {false, false};
     int slot = 0;
-    double *h_out = nullptr;                        // pinned
-    double *h_out_dev = nullptr;                    // device-visible alias of h_out (k_finish writes results straight to the host)
+    double *h_out = nullptr;                        // pinned, mapped: the synchronous path's k_finish writes results straight to the host
+    double *h_out_dev = nullptr;                    // its device-visible alias
+    double *h_params_dev[2] = {nullptr, nullptr};   // device-visible aliases of the staging slots (k_stage_params)
+    // The plan's device buffers are shared by every call on these chunks.  Calls may arrive on different streams (the
+    // library's own for the synchronous entry points, the caller's for imc_forward_batch_device): ev_done is recorded
+    // behind each call, and a call on another stream than its predecessor's first waits for it.
+    hipEvent_t ev_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
     hipGraphExec_t graph = nullptr;                 // captured enqueue(), replayed by run_batch
     uint64_t calls = 0;
     uint64_t lp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -600,6 +610,7 @@ struct Plan {
         for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
         dev_free(d_params); dev_free(d_out);
         for (int k = 0; k < 2; ++k) { (void)hipHostFree(h_params[k]); if (ev_params[k]) (void)hipEventDestroy(ev_params[k]); }
+        if (ev_done) (void)hipEventDestroy(ev_done);
         (void)hipHostFree(h_out);
     }
 };
@@ -769,8 +780,11 @@ struct PlanBuilder {
                             const double depths = (double)std::max<int>(1, (int)std::set<int>(kv.first->depth.begin() + o0->nsym, kv.first->depth.begin() + A).size());
                             // one ~4 us launch per depth; a cold step costs ~11 % more while one parameter set's table
                             // stays in an XCD's L2, ~17 % from the Infinity Cache (scratch microbenchmark)
+                            // (hybrid form; the streamed form - tables of the launch cache resident - runs every step
+                            // from the global table at ~6 % over the LDS-table kernel's step: measured at config[1])
                             const double cold_pen = table_bytes / B <= 3.6e6 ? 0.11 : 0.17;
-                            cost = depths * 4.0 + 8.0 + steps * t_step * (1.0 + cold_pen * cold);
+                            const bool streamed = g.z4_stream == 1 || (g.z4_stream < 0 && table_bytes <= Z4_STREAM_MAX_BYTES);
+                            cost = depths * 4.0 + 8.0 + steps * t_step * (streamed ? 1.06 : 1.0 + cold_pen * cold);
                         }
                         if (g.blocked_variant == 5 && !fits) cost *= 1e-3;      // tests: the hybrid table wherever it is possible
                         if (cost < best) { best = cost; best_l = l; }
@@ -1201,9 +1215,11 @@ struct PlanBuilder {
         if (e == hipSuccess) e = dev_alloc((void **)&q->d_params, (size_t)B * q->pstride * 8);
         if (e == hipSuccess) e = dev_alloc((void **)&q->d_out, (size_t)B * std::max(n_chunks, 1) * 8);
         for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-            e = hipHostMalloc((void **)&q->h_params[k], (size_t)B * q->pstride * 8, hipHostMallocDefault);
+            e = hipHostMalloc((void **)&q->h_params[k], (size_t)B * q->pstride * 8, hipHostMallocMapped);
+            if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&q->h_params_dev[k], q->h_params[k], 0);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&q->ev_params[k], hipEventDisableTiming);
         }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&q->ev_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_out, (size_t)B * std::max(n_chunks, 1) * 8, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&q->h_out_dev, q->h_out, 0);
         if (e != hipSuccess) {
@@ -1326,9 +1342,22 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
 {
     KernelChoice *kc = p->kc;
     const int N = p->N, S = p->S, NP = kc->NP, B = p->B;
-    HIP_TRY(hipMemcpyAsync(p->d_params, p->h_params[p->slot], (size_t)B * p->pstride * 8, hipMemcpyHostToDevice, stream));
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cap);
+    if (cap == hipStreamCaptureStatusNone && p->have_last && p->last_stream != stream)
+        HIP_TRY(hipStreamWaitEvent(stream, p->ev_done, 0));     // the plan's previous call ran on another stream
+    // Parameter upload.  Small sets (every BASELINE shape but the 64-proposal batch at N = 150) are fetched by a kernel
+    // from the mapped staging slot: a copy command costs its own ~3 us plus a ~10 us hand-over between the copy and the
+    // first kernel (rocprofv3 kernel trace), a kernel in the same queue costs one launch.
+    const size_t pbytes = (size_t)B * p->pstride * 8;
+    if (pbytes <= STAGE_KERNEL_MAX_BYTES) {
+        const unsigned n2 = (unsigned)(pbytes / 16);
+        hipLaunchKernelGGL(k_stage_params, dim3((n2 + 255) / 256), dim3(256), 0, stream,
+                           reinterpret_cast<const double2 *>(p->h_params_dev[p->slot]), reinterpret_cast<double2 *>(p->d_params), n2);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpyAsync(p->d_params, p->h_params[p->slot], pbytes, hipMemcpyHostToDevice, stream));
+    }
     if (cap == hipStreamCaptureStatusNone) {         // the slot may be rewritten once this upload has been consumed
         HIP_TRY(hipEventRecord(p->ev_params[p->slot], stream));
         p->ev_used[p->slot] = true;
@@ -1535,6 +1564,11 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
         HIP_TRY(hipEventRecord(ev.c, stream));
         g.events.push_back(ev);
     }
+    if (cap == hipStreamCaptureStatusNone) {
+        HIP_TRY(hipEventRecord(p->ev_done, stream));
+        p->last_stream = stream;
+        p->have_last = true;
+    }
     return IMC_OK;
 }
 
@@ -1567,16 +1601,44 @@ void collect_rank1_stats(Plan *p)
     }
 }
 
+// The caller of a synchronous entry point is waiting for the value.  k_finish writes the per-chunk results straight
+// into mapped host memory; the slots are set to a sentinel (a NaN payload no computation produces) before the launch
+// and the host polls them for up to two milliseconds - an evaluation of BASELINE config[1] takes 0.3 ms, and a
+// blocking hipStreamSynchronize returns some 15-20 us after the last kernel has finished - before it falls back to
+// the blocking wait.  The stream itself is idle a few microseconds later; later calls are ordered behind it anyway.
+constexpr uint64_t OUT_SENTINEL = 0x7ff8dead5e471e15ull;
+
+hipError_t wait_results(hipStream_t st, const double *h_out, size_t n)
+{
+    const volatile uint64_t *v = reinterpret_cast<const volatile uint64_t *>(h_out);
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t k = 0;
+    for (unsigned spin = 0;; ++spin) {
+        while (k < n && v[k] != OUT_SENTINEL) ++k;
+        if (k == n) { std::atomic_thread_fence(std::memory_order_acquire); return hipSuccess; }
+        if ((spin & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) return hipStreamSynchronize(st);
+    }
+}
+
 int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, const double *pis, const double *Ts,
               const double *Es, double *out_sum, double *out_per_chunk)
 {
     std::lock_guard<std::mutex> lk(g_mu);
+    static const bool dbg_host = std::getenv("IMC_DEBUG_HOST") != nullptr;     // diagnostics: host time per phase
+    static const int ab_sync = std::getenv("IMC_AB_SYNC") ? std::atoi(std::getenv("IMC_AB_SYNC")) : 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto h0 = now();
     if (int rc = ensure_ctx()) return rc;
     if (int rc = check_args(chunks, n_chunks, B, N, S, pis, Ts, Es)) return rc;
     HIP_TRY(hipSetDevice(g.device));
     Plan *p = nullptr;
     if (int rc = build_plan(chunks, n_chunks, N, S, B, false, &p)) return rc;
+    const auto h1 = now();
     if (int rc = stage_params(p, pis, Ts, Es, g.use_graphs)) return rc;
+    const size_t n_out = (size_t)B * n_chunks;
+    for (size_t k = 0; k < n_out; ++k) reinterpret_cast<volatile uint64_t *>(p->h_out)[k] = OUT_SENTINEL;
+    std::atomic_thread_fence(std::memory_order_release);
+    const auto h2 = now();
     // First call of a plan runs eagerly (kernel attributes get set); the second is captured into a hipGraph that
     // every later call replays: one graph launch instead of ~8 stream operations per evaluation.
     const bool use_graph = !g.profile && g.use_graphs && p->calls >= 1;
@@ -1596,8 +1658,22 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
     ++p->calls;
     for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
     g.last_kernels = p->kernels;
-    HIP_TRY(hipStreamSynchronize(g.stream));
+    const auto h3 = now();
+    if (ab_sync == 1 || !n_out) HIP_TRY(hipStreamSynchronize(g.stream));
+    else HIP_TRY(wait_results(g.stream, p->h_out, n_out));
+    const auto h4 = now();
     collect_rank1_stats(p);
+    if (dbg_host) {
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        static double acc[5] = {0, 0, 0, 0, 0};
+        static int n_acc = 0;
+        acc[0] += us(h0, h1); acc[1] += us(h1, h2); acc[2] += us(h2, h3); acc[3] += us(h3, h4); acc[4] += us(h4, now());
+        if (++n_acc % 20 == 0) {
+            fprintf(stderr, "[imc] host us per call: check+plan %.1f  stage %.1f  enqueue %.1f  sync wait %.1f  stats %.1f\n",
+                    acc[0] / 20, acc[1] / 20, acc[2] / 20, acc[3] / 20, acc[4] / 20);
+            for (double &a : acc) a = 0.0;
+        }
+    }
     for (int b = 0; b < B; ++b) {
         double tot = 0.0;   // Python sum(): left to right from 0 (likelihood.py:33)
         for (int f = 0; f < n_chunks; ++f) {
@@ -1625,7 +1701,7 @@ int run_state(const imc_obs *const *chunks, int n_chunks, bool op_mode, int B, i
     Plan *p = nullptr;
     if (int rc = build_plan(chunks, n_chunks, N, S, B, op_mode, &p)) return rc;
     if (int rc = stage_params(p, pis, Ts, Es, g.use_graphs)) return rc;
-    if (int rc = enqueue(p, g.stream, p->h_out_dev)) return rc;
+    if (int rc = enqueue(p, g.stream, p->d_out)) return rc;      // (the log-likelihoods are not read here)
     ++p->calls;
     for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
     g.last_kernels = p->kernels;
@@ -1868,7 +1944,10 @@ int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, 
     if (int rc = ensure_ctx()) return rc;
     if (int rc = check_args(chunks, n_chunks, B, N, S, pis, Ts, Es)) return rc;
     HIP_TRY(hipSetDevice(g.device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : g.stream;
+    // NULL is the default stream, as everywhere in HIP - NOT the library's own (non-blocking) stream: the caller goes on
+    // to use d_out_partial on the stream it named (torch's default stream has the handle 0), and work queued on a
+    // non-blocking stream would not be ordered before that use.
+    hipStream_t st = (hipStream_t)hip_stream;
     Plan *p = nullptr;
     if (int rc = build_plan(chunks, n_chunks, N, S, B, false, &p)) return rc;
     // no stream synchronisation here: the parameters go through the two-slot pinned staging (stage_params waits only

@@ -213,6 +213,13 @@ __global__ void k_export(const int32_t *final_vec, int n_chunks, int N, int NP, 
     }
 }
 
+// Parameter upload by kernel: `src` is the device-visible alias of a mapped, pinned staging slot on the host.
+__global__ void k_stage_params(const double2 *__restrict__ src, double2 *__restrict__ dst, unsigned n2)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n2) dst[i] = src[i];
+}
+
 // partial[b] = sum_f per_chunk[b][f], left to right from 0.0 (likelihood.py:33)
 __global__ void k_sum_chunks(const double *per_chunk, int n_chunks, int B, double *partial)
 {

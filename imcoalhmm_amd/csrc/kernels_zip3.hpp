@@ -195,6 +195,11 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
     const int len = valid ? (int)sd.len : 0;
     const bool first = (sd.first & SEG_FIRST) != 0;
     const uint8_t *tokp = sd.obs;
+    // (token loads as GLOBAL loads: through the descriptor's generic pointer they are flat loads, which also count
+    // against the LDS counter and turn every LDS wait behind them into a full one)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(1))) u32x4 *gptr4;
+    const __attribute__((address_space(1))) uint8_t *tokg = (const __attribute__((address_space(1))) uint8_t *)tokp;
 
     double P[NT][NT], Q[NT][NT];
     {
@@ -226,7 +231,10 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
     // end - and the identity entry wherever there is no token; `npos` positions are stepped (even, <= 16).
     auto masked_block = [&](int bi, int npos) __attribute__((always_inline)) {
         uint4 ob = make_uint4(0u, 0u, 0u, 0u);
-        if (bi * RESCALE_EVERY < len) ob = *reinterpret_cast<const uint4 *>(tokp + (size_t)bi * RESCALE_EVERY);
+        if (bi * RESCALE_EVERY < len) {
+            const u32x4 v = *(gptr4)(tokg + (size_t)bi * RESCALE_EVERY);
+            ob = make_uint4(v.x, v.y, v.z, v.w);
+        }
         const int live = len - bi * RESCALE_EVERY;              // positions u < live hold a token
         const int dead0 = (first && bi == 0) ? 0 : -1;
         const unsigned long long lo64 = (unsigned long long)ob.y << 32 | ob.x, hi64 = (unsigned long long)ob.w << 32 | ob.z;
@@ -241,8 +249,11 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
         zip3_rescale<NT>(P, ex);
     };
     if (maxlen > 0) masked_block(0, min(RESCALE_EVERY, (maxlen + 1) & ~1));
+    // (the tokens of block bi + 1 are requested while block bi runs; behind the last full block the load re-reads it)
+    u32x4 obn = nfull > 1 ? *(gptr4)(tokg + (size_t)RESCALE_EVERY) : u32x4{0u, 0u, 0u, 0u};
     for (int bi = 1; bi < nfull; ++bi) {
-        const uint4 ob = *reinterpret_cast<const uint4 *>(tokp + (size_t)bi * RESCALE_EVERY);
+        const u32x4 ob = obn;
+        obn = *(gptr4)(tokg + (size_t)min(bi + 1, nfull - 1) * RESCALE_EVERY);
         uint32_t w0 = ob.x, w1 = ob.y, w2 = ob.z, w3 = ob.w;
         zip3_load_row<NT>(arow, C + (size_t)(w0 & 0xffu) * TOK, 0, lo, lx);
 #pragma unroll 1

@@ -317,9 +317,11 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
         for (int u0 = 0; u0 < npos; u0 += PER) masked_run(bi, u0, min(PER, npos - u0));
         zip3_rescale<NT>(P, ex);
     };
-    if (maxlen > 0) masked_block(0, min(RESCALE_EVERY, (maxlen + 1) & ~1));
+    // Block 0 runs in the fast loop too when every segment of the wavefront has 16 tokens (position 0 of a chunk's first
+    // segment went into the start vector: that lane steps with the identity there); otherwise it is a masked block.
+    if (nfull == 0 && maxlen > 0) masked_block(0, min(RESCALE_EVERY, (maxlen + 1) & ~1));
     Z4_STAMP(2);
-    if (nfull > 1) {
+    if (nfull > 0) {
         // full blocks: the tokens of block bi + 1 are fetched while block bi runs, so the first token of the next block
         // is known a step ahead and the cold-operand pipeline never drains inside this loop.  The block's tokens sit
         // in a shift register of 32-bit words: four tokens - one word of bytes, two words of 16-bit ids - per iteration.
@@ -335,10 +337,10 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
             }
         };
         uint32_t cw[NW];
-        load_words(1, cw);
-        Z4Tok c0 = mk((int)(cw[0] & TM));
+        load_words(0, cw);
+        Z4Tok c0 = mk(first ? IDENT : (int)(cw[0] & TM));
         prime(c0);
-        for (int bi = 1; bi < nfull; ++bi) {
+        for (int bi = 0; bi < nfull; ++bi) {
             // Straight-line body (no load under a branch: the compiler then waits for exactly the loads it needs): the
             // next block's first token now (one word), its other words once this block's have been consumed; behind
             // the last full block both re-read the current block and the pipeline is pointed at the identity (the

@@ -69,6 +69,10 @@ class DistributedLikelihood(object):
             raise ValueError("reduction must be 'allreduce' or 'ordered'")
         self.reduction = reduction
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a single rank has nothing to reduce: the library's synchronous entry point writes the results straight into
+        # host memory (no device tensor, no reduction kernel, no device-to-host copy through torch)
+        self._direct = local_eval is None and self.world_size == 1 and not reduce_on_host
+        self._harr = None
 
     def _hip_eval(self, pis, Ts, Es):
         torch = self._torch
@@ -86,6 +90,8 @@ class DistributedLikelihood(object):
     def forward_params_batch(self, pis, Ts, Es):
         """Global log-likelihoods (float64[B]) for B parameter sets; collective over the group."""
         pis, Ts, Es = hmm._batch_params(pis, Ts, Es)
+        if self._direct:
+            return hmm.forward_chunks_batch([f.handle for f in self.forwarders], pis, Ts, Es)
         partial = self._local_eval(pis, Ts, Es)
         if self.reduce_on_host:
             partial = partial.cpu()
@@ -102,6 +108,13 @@ class DistributedLikelihood(object):
 
     def forward_params(self, pi, T, E):
         pi, T, E = hmm._params(pi, T, E)
+        if self._direct:
+            if self._harr is None:
+                self._harr = _capi.handle_array([f.handle for f in self.forwarders])
+            out = ctypes.c_double(0.0)
+            _capi.check(_capi.lib().imc_forward(self._harr, len(self.forwarders), pi.shape[0], E.shape[1],
+                                                _capi.dptr(pi), _capi.dptr(T), _capi.dptr(E), ctypes.byref(out)))
+            return out.value
         return float(self.forward_params_batch(pi[None], T[None], E[None])[0])
 
     def __call__(self, *parameters):

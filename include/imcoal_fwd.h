@@ -119,11 +119,14 @@ int imc_forward_batch_per_chunk(const imc_obs *const *chunks, int n_chunks, int 
                                 double *out_per_chunk);
 
 /* Multi-GPU building block: partial sums stay on the device.  d_out_partial is a DEVICE pointer
- * to B doubles, written on `hip_stream` (a hipStream_t, may be NULL for the library's stream);
- * the call returns after enqueueing (no stream synchronisation: the parameters are staged through two pinned
- * slots, so only a third call in flight waits for the first one's upload).  The caller then all-reduces
- * d_out_partial over ranks (RCCL sum).  Parameters are still host pointers.  Calls on one set of chunks must be
- * issued in stream order (they share the plan's device buffers). */
+ * to B doubles, written on `hip_stream` (a hipStream_t; NULL is the DEFAULT stream, as in every HIP call - torch's
+ * default stream has the handle 0 - and NOT the library's own non-blocking stream: the caller's next use of
+ * d_out_partial on the stream it named is ordered behind this call, and only that).  The call returns after
+ * enqueueing (no stream synchronisation: the parameters are staged through two pinned slots, so only a third call in
+ * flight waits for the first one's upload).  The caller then all-reduces d_out_partial over ranks (RCCL sum).
+ * Parameters are still host pointers.  Calls on one set of chunks share the plan's device buffers: a call on another
+ * stream than its predecessor's (including the synchronous entry points, which use the library's stream) first waits
+ * for the predecessor, so calls may move between streams; they run one after the other. */
 int imc_forward_batch_device(const imc_obs *const *chunks, int n_chunks, int B, int N, int S,
                              const double *pis, const double *Ts, const double *Es,
                              double *d_out_partial, void *hip_stream);

@@ -171,6 +171,30 @@ DEVICE_PATH = textwrap.dedent('''
         for b in range(2):
             ref = sum(oracle_lib.forward_scaled(pis[b], Ts[b], Es[b], c) for c in chunks)
             assert abs(got[b] - ref) / abs(ref) < 1e-11
+    # Stream ordering (round-2 bug: a NULL stream handle used to mean the library's own non-blocking stream, so work
+    # queued for torch's DEFAULT stream - handle 0 - was not ordered before torch's next use of the output tensor).
+    # A long chunk (the evaluation takes ~1 ms), five different parameter sets, every result read back through torch's
+    # own stream ordering ONLY: a stale or unfinished buffer cannot equal the synchronous value of its own set.
+    big = [Forwarder.from_array(synth.sample_alignment(*P("iso20_t0"), 30_000_000, seed=77), 3)]
+    hb = _capi.handle_array([f.handle for f in big])
+    want_big = [forward_chunks_batch([big[0].handle], *st) for st in sets]
+    assert stream == 0 or stream is None                 # torch's current stream here IS the default stream
+    out = torch.full((2,), float("nan"), dtype=torch.float64, device=dev)
+    for (pis, Ts, Es), want in zip(sets, want_big):
+        _capi.check(L.imc_forward_batch_device(hb, 1, 2, 20, 3, _capi.dptr(pis), _capi.dptr(Ts), _capi.dptr(Es),
+                                               ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)))
+        got = out.cpu().numpy()                          # no torch.cuda.synchronize(): the copy is ordered on the stream
+        assert np.array_equal(got, want), (got, want)
+    # ... on a side stream too, and alternating with the synchronous entry point (the plan's buffers are shared: a call
+    # on another stream than its predecessor's waits for it)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        for (pis, Ts, Es), want in zip(sets, want_big):
+            _capi.check(L.imc_forward_batch_device(hb, 1, 2, 20, 3, _capi.dptr(pis), _capi.dptr(Ts), _capi.dptr(Es),
+                                                   ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(side.cuda_stream)))
+            again = forward_chunks_batch([big[0].handle], pis, Ts, Es)      # library stream, right behind the side stream
+            got = out.cpu().numpy()
+            assert np.array_equal(got, want) and np.array_equal(again, want), (got, again, want)
     print("ok")
 ''') % (REPO, REPO)
 
