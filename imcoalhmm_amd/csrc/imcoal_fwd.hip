@@ -584,7 +584,7 @@ struct Plan {
     uint64_t chain_steps = 0;        // serial depth of the stitch (sum over levels of the longest chain)
     double *d_params = nullptr, *d_out = nullptr;
     // pinned staging of the caller's parameters: two slots used alternately, each guarded by an event recorded behind
-    // its upload, so a call only waits when the upload issued two calls earlier is still pending
+    // the call that read it, so a call only waits when the call issued two calls earlier is still running
     double *h_params[2] = {nullptr, nullptr};
     hipEvent_t ev_params[2] = {nullptr, nullptr};
     bool ev_used[2] = {false, false};
@@ -593,10 +593,10 @@ struct Plan {
     double *h_out_dev = nullptr;                    // its device-visible alias
     double *h_params_dev[2] = {nullptr, nullptr};   // device-visible aliases of the staging slots (k_stage_params)
     // The plan's device buffers are shared by every call on these chunks.  Calls may arrive on different streams (the
-    // library's own for the synchronous entry points, the caller's for imc_forward_batch_device): ev_done is recorded
-    // behind each call, and a call on another stream than its predecessor's first waits for it.
-    hipEvent_t ev_done = nullptr;
+    // library's own for the synchronous entry points, the caller's for imc_forward_batch_device): ev_params[slot] is
+    // recorded behind each call, and a call on another stream than its predecessor's first waits for it.
     hipStream_t last_stream = nullptr;
+    int last_slot = 0;
     bool have_last = false;
     hipGraphExec_t graph = nullptr;                 // captured enqueue(), replayed by run_batch
     uint64_t calls = 0;
@@ -610,7 +610,6 @@ struct Plan {
         for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
         dev_free(d_params); dev_free(d_out);
         for (int k = 0; k < 2; ++k) { (void)hipHostFree(h_params[k]); if (ev_params[k]) (void)hipEventDestroy(ev_params[k]); }
-        if (ev_done) (void)hipEventDestroy(ev_done);
         (void)hipHostFree(h_out);
     }
 };
@@ -1219,7 +1218,6 @@ struct PlanBuilder {
             if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&q->h_params_dev[k], q->h_params[k], 0);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&q->ev_params[k], hipEventDisableTiming);
         }
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&q->ev_done, hipEventDisableTiming);
         if (e == hipSuccess) e = hipHostMalloc((void **)&q->h_out, (size_t)B * std::max(n_chunks, 1) * 8, hipHostMallocMapped);
         if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&q->h_out_dev, q->h_out, 0);
         if (e != hipSuccess) {
@@ -1345,7 +1343,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cap);
     if (cap == hipStreamCaptureStatusNone && p->have_last && p->last_stream != stream)
-        HIP_TRY(hipStreamWaitEvent(stream, p->ev_done, 0));     // the plan's previous call ran on another stream
+        HIP_TRY(hipStreamWaitEvent(stream, p->ev_params[p->last_slot], 0));     // the plan's previous call ran on another stream
     // Parameter upload.  Small sets (every BASELINE shape but the 64-proposal batch at N = 150) are fetched by a kernel
     // from the mapped staging slot: a copy command costs its own ~3 us plus a ~10 us hand-over between the copy and the
     // first kernel (rocprofv3 kernel trace), a kernel in the same queue costs one launch.
@@ -1357,10 +1355,6 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
         HIP_TRY(hipGetLastError());
     } else {
         HIP_TRY(hipMemcpyAsync(p->d_params, p->h_params[p->slot], pbytes, hipMemcpyHostToDevice, stream));
-    }
-    if (cap == hipStreamCaptureStatusNone) {         // the slot may be rewritten once this upload has been consumed
-        HIP_TRY(hipEventRecord(p->ev_params[p->slot], stream));
-        p->ev_used[p->slot] = true;
     }
 
     uint64_t *lp = p->lp;
@@ -1565,8 +1559,13 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
         g.events.push_back(ev);
     }
     if (cap == hipStreamCaptureStatusNone) {
-        HIP_TRY(hipEventRecord(p->ev_done, stream));
+        // one event per call, behind its last kernel (an event record holds the queue for ~5 us: not in front of the
+        // first kernel): it marks the staging slot free again and orders the plan's next call if that comes on
+        // another stream
+        HIP_TRY(hipEventRecord(p->ev_params[p->slot], stream));
+        p->ev_used[p->slot] = true;
         p->last_stream = stream;
+        p->last_slot = p->slot;
         p->have_last = true;
     }
     return IMC_OK;
