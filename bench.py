@@ -32,6 +32,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 fp64 FMA lanes x 2 x 2.4 GHz; the fp64 MFMA peak is the same
 PIECE = 10_000_000             # synthetic alignments are generated in pieces of this many columns
+GEN_WORKERS = 0                # --gen-workers (0 = automatic)
 
 
 def parse_args(argv=None):
@@ -49,6 +50,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=1,
                     help="parameter sets evaluated per step (BASELINE config[4] uses 64 proposals/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-workers", type=int, default=0,
+                    help="processes that sample the synthetic alignments (0 = up to 16, forked before the first GPU call). "
+                         "Use 1 under rocprofv3 --pmc: the profiler initialises the GPU before Python starts, and a fork "
+                         "from a GPU-initialised process can hang")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs leg (profiling runs)")
     ap.add_argument("--no-compress", action="store_true",
                     help="raw symbol stream (one step per alignment column), kernel chosen automatically")
@@ -92,7 +97,7 @@ def generate(requests):
         for k, off in enumerate(range(0, cols, PIECE)):
             tasks.append((key, min(PIECE, cols - off), seed * 1000 + k))
             index.append(tag)
-    workers = max(1, min(len(tasks), os.cpu_count() or 1, 16))
+    workers = max(1, min(len(tasks), os.cpu_count() or 1, 16, GEN_WORKERS or 16))
     if workers > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(workers) as pool:
@@ -132,6 +137,8 @@ def timed_steps(lib, step, steps, warmup, fence):
 
 def main():
     args = parse_args()
+    global GEN_WORKERS
+    GEN_WORKERS = args.gen_workers
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     world_env = os.environ.get("WORLD_SIZE")
