@@ -163,7 +163,9 @@ int imc_set_compression(int mode);
 int imc_dictionary_reset(void);
 /* Kernel timing with HIP events on the launch stream.  After imc_profile_enable(1) every
  * propagate/stitch launch is bracketed by events; imc_profile_read synchronises, returns the
- * accumulated device milliseconds and launch counts since the last reset, and resets. */
+ * accumulated device milliseconds and launch counts since the last reset, and resets.  ms_propagate is the
+ * propagate kernel(s) of a call; k_zpropagate4's separate table launches (k_z4_raw, k_z4_level) lie in front of
+ * the bracket, so the figure is the scan launch's own duration. */
 int imc_profile_enable(int on);
 int imc_profile_read(double *ms_propagate, double *ms_stitch, uint64_t *n_propagate, uint64_t *n_stitch);
 /* Rank-one hand-off of the GEMM-chain kernels (long segments, N > 24): a segment's transfer operator is tested at a
