@@ -282,6 +282,17 @@ void obs_release(imc_obs *o)
 // Build a chunk from validated host symbols.  Called WITHOUT g_mu: the O(L) host work (dictionary training, the
 // multi-level encoding: ~1.4 s at 1e8 columns) runs unlocked so that other threads keep evaluating; the lock is
 // taken only to read / publish the shared dictionary and for the HIP calls on the library's stream.
+// A pair becomes a 16-bit token when it occurs this often in the training sample: DICT_WIDE_MIN_COUNT in a full
+// sample, fewer in a short one - the dictionary of the FIRST chunk serves every later chunk of the alphabet, and a
+// workload of many 1e7-column chunks (BASELINE config[3]) trains on one of them: with the full-sample threshold it got
+// 1553 tokens (141 columns per token), with 3 occurrences 3473 (155) and a 3 % shorter evaluation; a token that turns
+// out to be rare costs one table entry.  (IMC_DICT_MIN_COUNT overrides: experiments.)
+size_t wide_min_count(size_t sample_tokens)
+{
+    if (const char *e = std::getenv("IMC_DICT_MIN_COUNT")) return (size_t)std::max(1, std::atoi(e));
+    return sample_tokens >= 400000 ? DICT_WIDE_MIN_COUNT : sample_tokens >= 200000 ? 4 : 3;
+}
+
 int obs_upload(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym, imc_obs **out)
 {
     // exactly one of host (alphabets up to 256: bytes) and host16 (larger alphabets) is non-null when L > 0
@@ -312,7 +323,7 @@ int obs_upload(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym
                 const size_t cols = std::min(L, DICT_WIDE_TRAIN_TOKENS * 96);   // a byte-level token covers ~60-100 columns
                 const std::vector<uint8_t> lvl256 = imc::encode_bytes(nd->dict, host, cols, nullptr);
                 const size_t nt = std::min(lvl256.size() - 1, DICT_WIDE_TRAIN_TOKENS);
-                imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), DICT_WIDE_MIN_COUNT);
+                imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), wide_min_count(nt));
             }
         }
         nd->depth.assign(nd->dict.alphabet, 0);

@@ -725,69 +725,136 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
     long long ex = tail ? (long long)a.EX[gv + (c0 < a.N ? c0 : 0)] : 0;
     int which = 0;
     const int t_begin = tail ? a.t_from : first ? 1 : 0;
+    // Shapes with NT >= 8 take their A fragments straight from global memory (below); the smaller ones, whose tiles are
+    // all dealt round-robin (one fragment per tile: too many registers), keep the LDS-staged panels.
+    constexpr bool DIRECT_A = ROWS;
+    // A fragments straight from the (L2-resident) operator table into registers, one 16-deep panel ahead: a tile-row
+    // belongs to ONE wavefront (only the rows beyond 8 are dealt tile by tile), so nothing is shared through LDS and
+    // the k loop runs without a barrier - the LDS-staged panels cost one __syncthreads per panel, ten per step at
+    // N = 150, and a step ran at 72 % of its MFMA time.  Fragment f: f = 0 the wavefront's own tile-row (ROWS), then one
+    // per dealt tile; lane (lm, lg) takes A[16 tr + lm][16 kb + 4 lg .. +3] (32 contiguous bytes, four lanes a line).
+    constexpr int NF = DIRECT_A ? 1 + (JMAX - JROW) : 1;
+    size_t fo[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        const int j = ROWS ? (f == 0 ? 0 : JROW + f - 1) : f;
+        fo[f] = (size_t)(a_off[j] / APS) * NP + 4 * lg;          // a_off[j] = (16 tr + lm) * APS + 4 lg
+    }
+    double2 fn[NF][2];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) fn[f][0] = fn[f][1] = double2{0.0, 0.0};
+    auto fetch = [&](const double *A, int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const double2 *src = reinterpret_cast<const double2 *>(A + fo[f] + kb * 16);
+            fn[f][0] = src[0];
+            fn[f][1] = src[1];
+        }
+    };
+    int tok = t_begin < t_end ? seg_token(tokp, wide, t_begin) : 0;
     double2 sa[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) sa[k] = double2{0.0, 0.0};
     if (t_begin < t_end) {
-        const double *A0 = Ct + (size_t)seg_token(tokp, wide, t_begin) * NP * NP;
+        const double *A0 = Ct + (size_t)tok * NP * NP;
+        if constexpr (DIRECT_A) fetch(A0, 0);
+        else {
 #pragma unroll
-        for (int k = 0; k < EPT; ++k)
-            if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(A0 + gAo[k]);
+            for (int k = 0; k < EPT; ++k)
+                if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(A0 + gAo[k]);
+        }
     }
     for (int t = t_begin; t < t_end; ++t) {
-        const int tok = seg_token(tokp, wide, t);
-        const double *A = Ct + (size_t)tok * NP * NP;
+        int cex_cur = 0;
         v4f64 acc[JMAX];
 #pragma unroll
         for (int j = 0; j < JMAX; ++j) acc[j] = v4f64{0.0, 0.0, 0.0, 0.0};
+        if constexpr (DIRECT_A) {
+            const double *A = Ct + (size_t)tok * NP * NP;
+            cex_cur = cex[tok];
+            const int tok_next = t + 1 < t_end ? seg_token(tokp, wide, t + 1) : tok;
+            const double *An = Ct + (size_t)tok_next * NP * NP;
+#pragma unroll 2
+            for (int kb = 0; kb < NP / 16; ++kb) {
+                double2 fc[NF][2];
 #pragma unroll
-        for (int k = 0; k < EPT; ++k)
-            if (act[k]) *reinterpret_cast<double2 *>(Apan + lA[k]) = sa[k];
-        __syncthreads();
+                for (int f = 0; f < NF; ++f) { fc[f][0] = fn[f][0]; fc[f][1] = fn[f][1]; }
+                if (kb + 1 < NP / 16) fetch(A, kb + 1);
+                else fetch(An, 0);                                   // the next token's first panel (last step: a harmless reload)
+                const double *Bk = slab + (size_t)kb * 16 * SPS;
+                if constexpr (ROWS) {   // the wavefront's own tile-row: one A fragment for TCS tiles
+                    const double av[4] = {fc[0][0].x, fc[0][0].y, fc[0][1].x, fc[0][1].y};
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+                        for (int j = 0; j < JROW; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[b_off[0] + s2 * SPS + j * 16], acc[j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int j = JROW; j < JMAX; ++j) {
+                    if (j < n_own) {   // wave-uniform
+                        const int f = (ROWS ? 1 : 0) + j - JROW;
+                        const double av[4] = {fc[f][0].x, fc[f][0].y, fc[f][1].x, fc[f][1].y};
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2)
+                            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[b_off[j] + s2 * SPS], acc[j], 0, 0, 0);
+                    }
+                }
+            }
+            tok = tok_next;
+        } else {
+            const int tok_l = seg_token(tokp, wide, t);
+            const double *A = Ct + (size_t)tok_l * NP * NP;
+            cex_cur = cex[tok_l];
+#pragma unroll
+            for (int k = 0; k < EPT; ++k)
+                if (act[k]) *reinterpret_cast<double2 *>(Apan + lA[k]) = sa[k];
+            __syncthreads();
 #pragma unroll 1
-        for (int kb = 0; kb < NP / 16; ++kb) {
-            const int buf = kb & 1;
-            if (kb + 1 < NP / 16) {
+            for (int kb = 0; kb < NP / 16; ++kb) {
+                const int buf = kb & 1;
+                if (kb + 1 < NP / 16) {
 #pragma unroll
-                for (int k = 0; k < EPT; ++k)
-                    if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(A + gAo[k] + (kb + 1) * 16);
-            }
-            const double *Al = Apan + buf * G::A_DOUBLES;
-            const double *Bk = slab + (size_t)kb * 16 * SPS;
-            if constexpr (ROWS) {   // the wavefront's own tile-row: one A fragment for TCS tiles
-                const double2 *ap = reinterpret_cast<const double2 *>(Al + a_off[0]);
-                const double2 a01 = ap[0], a23 = ap[1];
-                const double av[4] = {a01.x, a01.y, a23.x, a23.y};
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2)
-#pragma unroll
-                    for (int j = 0; j < JROW; ++j)
-                        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[b_off[0] + s2 * SPS + j * 16], acc[j], 0, 0, 0);
-            }
-#pragma unroll
-            for (int j = JROW; j < JMAX; ++j) {
-                if (j < n_own) {   // wave-uniform
-                    const double2 *ap = reinterpret_cast<const double2 *>(Al + a_off[j]);
+                    for (int k = 0; k < EPT; ++k)
+                        if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(A + gAo[k] + (kb + 1) * 16);
+                }
+                const double *Al = Apan + buf * G::A_DOUBLES;
+                const double *Bk = slab + (size_t)kb * 16 * SPS;
+                if constexpr (ROWS) {   // the wavefront's own tile-row: one A fragment for TCS tiles
+                    const double2 *ap = reinterpret_cast<const double2 *>(Al + a_off[0]);
                     const double2 a01 = ap[0], a23 = ap[1];
                     const double av[4] = {a01.x, a01.y, a23.x, a23.y};
 #pragma unroll
                     for (int s2 = 0; s2 < 4; ++s2)
-                        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[b_off[j] + s2 * SPS], acc[j], 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < JROW; ++j)
+                            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[b_off[0] + s2 * SPS + j * 16], acc[j], 0, 0, 0);
                 }
+#pragma unroll
+                for (int j = JROW; j < JMAX; ++j) {
+                    if (j < n_own) {   // wave-uniform
+                        const double2 *ap = reinterpret_cast<const double2 *>(Al + a_off[j]);
+                        const double2 a01 = ap[0], a23 = ap[1];
+                        const double av[4] = {a01.x, a01.y, a23.x, a23.y};
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2)
+                            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[b_off[j] + s2 * SPS], acc[j], 0, 0, 0);
+                    }
+                }
+                if (kb + 1 < NP / 16) {
+                    double *An = Apan + (buf ^ 1) * G::A_DOUBLES;
+#pragma unroll
+                    for (int k = 0; k < EPT; ++k)
+                        if (act[k]) *reinterpret_cast<double2 *>(An + lA[k]) = sa[k];
+                }
+                __syncthreads();
             }
-            if (kb + 1 < NP / 16) {
-                double *An = Apan + (buf ^ 1) * G::A_DOUBLES;
+            if (t + 1 < t_end) {   // prefetch the next token's first panel
+                const double *An = Ct + (size_t)seg_token(tokp, wide, t + 1) * NP * NP;
 #pragma unroll
                 for (int k = 0; k < EPT; ++k)
-                    if (act[k]) *reinterpret_cast<double2 *>(An + lA[k]) = sa[k];
+                    if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(An + gAo[k]);
             }
-            __syncthreads();
-        }
-        if (t + 1 < t_end) {   // prefetch the next token's first panel
-            const double *An = Ct + (size_t)seg_token(tokp, wide, t + 1) * NP * NP;
-#pragma unroll
-            for (int k = 0; k < EPT; ++k)
-                if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(An + gAo[k]);
         }
         // one power-of-two scale for the slab: exponent of its largest entry
         double mx = 0.0;
@@ -817,7 +884,7 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
 #pragma unroll
                 for (int q = 0; q < 4; ++q) slab[w_off[j] + 4 * q * SPS] = ldexp(acc[j][q], -e);
             }
-        ex += cex[tok] + e;
+        ex += cex_cur + e;
         __syncthreads();
     }
     // results -> level 0: operator block state-major [i][c] (N x NP), or the vector [i] for a first segment
