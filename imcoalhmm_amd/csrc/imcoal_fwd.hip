@@ -93,7 +93,8 @@ constexpr size_t R1_MIN_SEGLEN = 1024;             // rank-one hand-off: segment
 constexpr size_t R1_MIN_HEAD = 256;                // ... run at least this many on the GEMM chain before the test
 constexpr double R1_HEAD_COLUMNS = 65536.0;        // planner's estimate of the columns a head needs before it collapses
 constexpr double R1_HEAD_MIN_COLUMNS = 8192.0;     // first checkpoint of the hand-off test, in alignment columns
-constexpr int R1_MAX_ROUNDS = 20;                  // checkpoints per evaluation (each ~1.25x the previous one)
+constexpr int R1_MAX_ROUNDS = 24;                  // checkpoints per evaluation
+constexpr double R1_DENSE_COLUMNS = 1.0e5;         // ... spaced 1.125x up to this many alignment columns, 1.5x beyond
 
 hipError_t dev_alloc(void **p, size_t bytes);
 void dev_free(void *p);
@@ -980,12 +981,15 @@ struct PlanBuilder {
                         gr.rank1 = true;
                         gr.head_len = (int)head;
                         gr.seglen = std::max<size_t>(16, round_up(gr.seglen / best_m, 16));
-                        // checkpoints: from ~8k alignment columns, each ~1.25x the previous (multiples of 16 tokens),
-                        // while at least an eighth of the segment would still be left for the mat-vec chain
+                        // checkpoints: from ~8k alignment columns, each ~1.125x the previous (multiples of 16 tokens)
+                        // up to ~100k columns - where the operators of the measured models collapse; a failing check
+                        // is a quick reject and costs two near-empty launches - then 1.5x, while at least an eighth
+                        // of the segment would still be left for the mat-vec chain
                         size_t c = round_up(std::max<size_t>(64, (size_t)(R1_HEAD_MIN_COLUMNS / span)), 16);
                         while ((int)gr.checkpoints.size() < R1_MAX_ROUNDS && c + gr.seglen / 8 < gr.seglen) {
                             gr.checkpoints.push_back((int)c);
-                            c = round_up(c + std::max<size_t>(16, c / 4), 16);
+                            const size_t step = (double)c * span < R1_DENSE_COLUMNS ? c / 8 : c / 2;
+                            c = round_up(c + std::max<size_t>(16, step), 16);
                         }
                         if (gr.checkpoints.empty()) gr.rank1 = false;
                     }
@@ -1453,7 +1457,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                 for (size_t r = 0; r < gr.checkpoints.size(); ++r) {
                     HIP_TRY(hipGetLastError());
                     ba.t_to = gr.checkpoints[r];
-                    hipLaunchKernelGGL(k_rank1_check, dim3((unsigned)gr.tail_blocks.size(), (unsigned)B), dim3(256), 0, stream, ba,
+                    hipLaunchKernelGGL(k_rank1_check, dim3((unsigned)gr.tail_blocks.size(), (unsigned)B), dim3(1024), 0, stream, ba,
                                        (const BigBlock *)gr.d_tail_blocks, NP);
                     HIP_TRY(hipGetLastError());
                     ba.t_from = gr.checkpoints[r];

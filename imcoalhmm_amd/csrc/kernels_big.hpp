@@ -917,7 +917,7 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
 // the data alone - identical inputs give identical decisions (and bits), there is no state carried between calls.
 static constexpr double R1_TOL = 2.2737367544323206e-13;   // 2^-42
 
-__global__ __launch_bounds__(256) void k_rank1_check(BigArgs a, const BigBlock *blocks, int NP)
+__global__ __launch_bounds__(1024) void k_rank1_check(BigArgs a, const BigBlock *blocks, int NP)
 {
     __shared__ double s_sum[256];
     __shared__ int s_star;
@@ -930,10 +930,40 @@ __global__ __launch_bounds__(256) void k_rank1_check(BigArgs a, const BigBlock *
     const size_t gv = (size_t)b * a.n_vecs_total + bk.out_vec0;
     const double *P = a.P + gv * NP;
     const int N = a.N;
-    for (int c = tid; c < N; c += blockDim.x) {
-        double t = 0.0;
-        for (int i = 0; i < N; ++i) t += P[(size_t)i * NP + c];
-        s_sum[c] = t;
+    // Quick reject (most checkpoints of most segments are too early): two columns of a certifiable operator are
+    // proportional row by row to ~5e-13, so a spread of the row ratios P[i][N/2] / P[i][0] beyond 1e-9 (relative) -
+    // three thousand times the tolerance of the real test below - means "not yet" without reading the whole block.
+    if (N >= 2) {
+        __shared__ double s_lo[256], s_hi[256];
+        double lo = INFINITY, hi = 0.0;
+        for (int i = tid; i < N; i += 256) {
+            const double p0 = P[(size_t)i * NP], p1 = P[(size_t)i * NP + N / 2];
+            if (p0 > 0.0 && p1 > 0.0 && p0 < INFINITY && p1 < INFINITY) {
+                const double q = p1 / p0;
+                lo = fmin(lo, q);
+                hi = fmax(hi, q);
+            }
+        }
+        if (tid < 256) { s_lo[tid] = lo; s_hi[tid] = hi; }
+        __syncthreads();
+        for (int h = 128; h >= 1; h >>= 1) {
+            if (tid < h) { s_lo[tid] = fmin(s_lo[tid], s_lo[tid + h]); s_hi[tid] = fmax(s_hi[tid], s_hi[tid + h]); }
+            __syncthreads();
+        }
+        if (s_hi[0] > 0.0 && s_hi[0] - s_lo[0] > 1e-9 * s_hi[0]) return;      // (workgroup-uniform)
+    }
+    // column sums: four row quarters per column in parallel, added in a fixed order (bit-identical repeats)
+    {
+        __shared__ double s_part[4][256];
+        const int c = tid & 255, part = tid >> 8;                     // blockDim.x = 1024
+        if (c < N) {
+            const int i0 = (N * part) / 4, i1 = (N * (part + 1)) / 4;
+            double t = 0.0;
+            for (int i = i0; i < i1; ++i) t += P[(size_t)i * NP + c];
+            s_part[part][c] = t;
+        }
+        __syncthreads();
+        if (tid < N) s_sum[tid] = ((s_part[0][tid] + s_part[1][tid]) + s_part[2][tid]) + s_part[3][tid];
     }
     if (tid == 0) s_bad = 0u;
     __syncthreads();
@@ -941,8 +971,10 @@ __global__ __launch_bounds__(256) void k_rank1_check(BigArgs a, const BigBlock *
     // N <= 256 columns, one per thread, folded through LDS
     {
         __shared__ int s_idx[256], s_ex[256];
-        s_idx[tid] = tid < N ? tid : -1;
-        s_ex[tid] = tid < N ? a.EX[gv + tid] : 0;
+        if (tid < 256) {
+            s_idx[tid] = tid < N ? tid : -1;
+            s_ex[tid] = tid < N ? a.EX[gv + tid] : 0;
+        }
         __syncthreads();
         for (int h = 128; h >= 1; h >>= 1) {
             if (tid < h) {
