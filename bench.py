@@ -397,7 +397,7 @@ def extra_configs(lib, d, data, fence):
     config[2] (150 states, 1 x 1e8 columns), the per-GPU slice of config[3] (20 states, 32 x 1e7) and of config[4]
     (150 states, 64 proposals x 32 x 1e6).  `value` is columns/s (column-evaluations/s for the batch)."""
     from imcoalhmm_amd import Forwarder, _capi
-    from imcoalhmm_amd.hmm import forward_chunks, forward_chunks_batch
+    from imcoalhmm_amd.hmm import forward_chunks, forward_chunks_batch, recompress
     res = []
 
     def run(workload, fw, fn, cols, batch, steps, warmup):
@@ -405,11 +405,15 @@ def extra_configs(lib, d, data, fence):
         plan = _capi.last_plan()
         res.append({"workload": workload, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
                     "value": cols * batch * steps / elapsed, "unit": "columns/s" if batch == 1 else "column-evaluations/s",
-                    "kernel": plan["kernels"], "kernel_ms": k_ms, "stitch_ms": s_ms, "loglik": value})
+                    "kernel": plan["kernels"], "kernel_ms": k_ms, "stitch_ms": s_ms, "loglik": value,
+                    "token_alphabet": plan["token_alphabet"],
+                    "columns_per_token": (sum(len(f) for f in fw) / max(sum(f.compressed_length(plan["token_alphabet"])[0] for f in fw), 1))
+                                         if plan["vector_tokens"] else 1.0})
 
     # config[2]: ~150 states (IsolationMigrationModel(75, 75)), one 1e8-column alignment
     pi, T, E = d["im150_t0_pi"], d["im150_t0_T"], d["im150_t0_E"]
     t0 = time.time()
+    _capi.check(lib.imc_dictionary_reset())       # every configuration compresses with a dictionary of its own data
     fw = [Forwarder.from_array(data.pop("c3"), 3)]
     h = [f.handle for f in fw]
     run("initial-migration-model 150 states, 1 x 100000000-column synthetic alignment (BASELINE config[2])", fw,
@@ -420,7 +424,9 @@ def extra_configs(lib, d, data, fence):
     # config[3] slice: 20 states, 32 x 1e7 columns (what one of 8 GPUs holds of the 256 chunks)
     pi20, T20, E20 = d["iso20_t0_pi"], d["iso20_t0_T"], d["iso20_t0_E"]
     t0 = time.time()
+    _capi.check(lib.imc_dictionary_reset())
     fw = [Forwarder.from_array(data.pop("c4_%d" % i), 3) for i in range(32)]
+    recompress(fw)                                # what Likelihood(model, forwarders) does: one dictionary from all chunks
     h = [f.handle for f in fw]
     run("isolation-model 20 states, 32 x 10000000-column synthetic chunks (per-GPU slice of BASELINE config[3])", fw,
         lambda: forward_chunks(h, pi20, T20, E20), 3.2e8, 1, 5, 2)
@@ -429,7 +435,9 @@ def extra_configs(lib, d, data, fence):
     # config[4] slice: 150 states, 64 proposals per step x 32 x 1e6 columns
     pis, Ts, Es, ms = proposals(d, "im150_t0", 150, 64)
     t0 = time.time()
+    _capi.check(lib.imc_dictionary_reset())
     fw = [Forwarder.from_array(data.pop("c5_%d" % i), 3) for i in range(32)]
+    recompress(fw)
     h = [f.handle for f in fw]
     run("initial-migration-model 150 states, 64 proposals/step x 32 x 1000000-column chunks (per-GPU slice of BASELINE config[4])",
         fw, lambda: float(forward_chunks_batch(h, pis, Ts, Es)[0]), 3.2e7, 64, 2, 1)

@@ -70,6 +70,7 @@ SIGNATURES = [
     ("imc_set_rank1_handoff", ctypes.c_int, [ctypes.c_int]),
     ("imc_set_blocked_kernel", ctypes.c_int, [ctypes.c_int]),
     ("imc_set_table_streaming", ctypes.c_int, [ctypes.c_int]),
+    ("imc_obs_recompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("imc_last_plan", ctypes.c_int, [_u64p]),
     ("imc_last_kernels", ctypes.c_char_p, []),
 ]

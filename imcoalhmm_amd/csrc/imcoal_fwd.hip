@@ -270,14 +270,23 @@ hipError_t upload_padded(const uint8_t *host, size_t n, uint8_t **dptr)
     return e;
 }
 
-void obs_release(imc_obs *o)
+void release_tokens(imc_obs *o)          // the chunk falls back to its raw symbols
 {
-    dev_free(o->d_sym);
     for (int l = 0; l < imc::kNumLevels; ++l) {
         bool alias = false;
         for (int m = 0; m < l; ++m) alias |= (o->d_tok[m] == o->d_tok[l]);
         if (o->d_tok[l] && !alias) dev_free(o->d_tok[l]);
     }
+    for (int l = 0; l < imc::kNumLevels; ++l) {
+        o->d_tok[l] = nullptr; o->wide[l] = false; o->ntok[l] = 0; o->alphabet[l] = o->nsym; o->tok_count[l].clear();
+    }
+    o->dict.reset();
+}
+
+void obs_release(imc_obs *o)
+{
+    dev_free(o->d_sym);
+    release_tokens(o);
 }
 
 // Build a chunk from validated host symbols.  Called WITHOUT g_mu: the O(L) host work (dictionary training, the
@@ -292,6 +301,83 @@ size_t wide_min_count(size_t sample_tokens)
 {
     if (const char *e = std::getenv("IMC_DICT_MIN_COUNT")) return (size_t)std::max(1, std::atoi(e));
     return sample_tokens >= 400000 ? DICT_WIDE_MIN_COUNT : sample_tokens >= 200000 ? 4 : 3;
+}
+
+// Train a pair dictionary on host symbols (exactly one of host / host16 is non-null); host work only.
+std::shared_ptr<DictDev> make_dictionary(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym)
+{
+    auto nd = std::make_shared<DictDev>();
+    if (host16) {                                    // symbols are not bytes: straight to the 16-bit rounds on the raw stream
+        imc::init_dict(nd->dict, nsym);
+        const size_t nt = std::min(L - 1, DICT_WIDE_TRAIN_TOKENS * 8);
+        imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(host16 + 1, host16 + 1 + nt), DICT_WIDE_MIN_COUNT);
+    } else {
+        const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
+        imc::train_dict(nd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64);
+        if (nd->dict.alphabet >= imc::kByteAlphabet) {   // 16-bit tokens: rounds over the whole chunk's byte-level stream
+            const size_t cols = std::min(L, DICT_WIDE_TRAIN_TOKENS * 96);   // a byte-level token covers ~60-100 columns
+            const std::vector<uint8_t> lvl256 = imc::encode_bytes(nd->dict, host, cols, nullptr);
+            const size_t nt = std::min(lvl256.size() - 1, DICT_WIDE_TRAIN_TOKENS);
+            imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), wide_min_count(nt));
+        }
+    }
+    nd->depth.assign(nd->dict.alphabet, 0);
+    for (int z = nsym; z < nd->dict.alphabet; ++z)
+        nd->depth[z] = 1 + std::max(nd->depth[nd->dict.left[z]], nd->depth[nd->dict.right[z]]);
+    for (int z = nsym; z < nd->dict.alphabet; ++z) nd->order.push_back((uint16_t)z);
+    std::stable_sort(nd->order.begin(), nd->order.end(),
+                     [&](uint16_t x, uint16_t y) { return nd->depth[x] < nd->depth[y]; });
+    return nd;
+}
+
+// Device copy of a freshly trained dictionary (g_mu held, context ready).
+int upload_dictionary(const std::shared_ptr<DictDev> &nd)
+{
+    HIP_TRY(hipSetDevice(g.device));
+    nd->pid = g.pid;
+    nd->dict.id = g.next_dict_id++;
+    const size_t abytes = (size_t)nd->dict.alphabet * sizeof(uint16_t);
+    hipError_t e2 = dev_alloc((void **)&nd->d_left, abytes);
+    if (e2 == hipSuccess) e2 = dev_alloc((void **)&nd->d_right, abytes);
+    if (e2 == hipSuccess) e2 = hipMemcpy(nd->d_left, nd->dict.left.data(), abytes, hipMemcpyHostToDevice);
+    if (e2 == hipSuccess) e2 = hipMemcpy(nd->d_right, nd->dict.right.data(), abytes, hipMemcpyHostToDevice);
+    if (e2 == hipSuccess) e2 = dev_alloc((void **)&nd->d_order, std::max<size_t>(abytes, 16));
+    if (e2 == hipSuccess && !nd->order.empty())
+        e2 = hipMemcpy(nd->d_order, nd->order.data(), nd->order.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e2 != hipSuccess) return fail(IMC_ERR_HIP, std::string("dictionary upload: ") + hipGetErrorString(e2));
+    return IMC_OK;
+}
+
+// The token streams of `enc` (encoded with dd's dictionary) become chunk o's (g_mu held).  On failure the chunk has no
+// token streams left (it evaluates on its raw symbols).
+int install_encoding(imc_obs *o, const std::shared_ptr<DictDev> &dd, const imc::EncodedLevels &enc)
+{
+    const int nsym = o->nsym;
+    o->dict = dd;
+    for (int l = 0; l < imc::kNumLevels; ++l) {
+        o->alphabet[l] = enc.alphabet[l];
+        o->ntok[l] = enc.length[l];
+        o->wide[l] = enc.is_wide[l];
+        o->tok_count[l].clear();
+        if (l > 0 && enc.alphabet[l] == enc.alphabet[l - 1]) { o->d_tok[l] = o->d_tok[l - 1]; o->wide[l] = o->wide[l - 1]; o->tok_count[l] = o->tok_count[l - 1]; continue; }
+        if (enc.alphabet[l] <= nsym) { o->d_tok[l] = nullptr; continue; }   // raw stream: use d_sym
+        if (!enc.is_wide[l]) {
+            o->tok_count[l].assign((size_t)enc.alphabet[l], 0u);
+            for (size_t t = 1; t < enc.length[l]; ++t) o->tok_count[l][enc.bytes[l][t]]++;   // (position 0 is a raw symbol)
+        } else if (enc.alphabet[l] <= HYBRID_MAX_ALPHABET) {
+            o->tok_count[l].assign((size_t)enc.alphabet[l], 0u);
+            for (size_t t = 1; t < enc.length[l]; ++t) o->tok_count[l][enc.wide[l][t]]++;
+        }
+        hipError_t e3 = enc.is_wide[l]
+            ? upload_padded(reinterpret_cast<const uint8_t *>(enc.wide[l].data()), enc.length[l] * sizeof(imc::tok_t), &o->d_tok[l])
+            : upload_padded(enc.bytes[l].data(), enc.length[l], &o->d_tok[l]);
+        if (e3 != hipSuccess) {
+            release_tokens(o);
+            return fail(e3 == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
+                        std::string("token stream upload: ") + hipGetErrorString(e3));
+        }
+    }
+    return IMC_OK;
 }
 
 int obs_upload(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym, imc_obs **out)
@@ -312,43 +398,12 @@ int obs_upload(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym
         }
     }
     if (train) {                                        // host only, unlocked
-        auto nd = std::make_shared<DictDev>();
-        if (wide_raw) {                                  // symbols are not bytes: straight to the 16-bit rounds on the raw stream
-            imc::init_dict(nd->dict, nsym);
-            const size_t nt = std::min(L - 1, DICT_WIDE_TRAIN_TOKENS * 8);
-            imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(host16 + 1, host16 + 1 + nt), DICT_WIDE_MIN_COUNT);
-        } else {
-            const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
-            imc::train_dict(nd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64);
-            if (nd->dict.alphabet >= imc::kByteAlphabet) {   // 16-bit tokens: rounds over the whole chunk's byte-level stream
-                const size_t cols = std::min(L, DICT_WIDE_TRAIN_TOKENS * 96);   // a byte-level token covers ~60-100 columns
-                const std::vector<uint8_t> lvl256 = imc::encode_bytes(nd->dict, host, cols, nullptr);
-                const size_t nt = std::min(lvl256.size() - 1, DICT_WIDE_TRAIN_TOKENS);
-                imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), wide_min_count(nt));
-            }
-        }
-        nd->depth.assign(nd->dict.alphabet, 0);
-        for (int z = nsym; z < nd->dict.alphabet; ++z)
-            nd->depth[z] = 1 + std::max(nd->depth[nd->dict.left[z]], nd->depth[nd->dict.right[z]]);
-        for (int z = nsym; z < nd->dict.alphabet; ++z) nd->order.push_back((uint16_t)z);
-        std::stable_sort(nd->order.begin(), nd->order.end(),
-                         [&](uint16_t x, uint16_t y) { return nd->depth[x] < nd->depth[y]; });
+        auto nd = make_dictionary(host, host16, L, nsym);
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g.dicts.find(nsym);
         if (it != g.dicts.end()) dd = it->second;       // another thread published one meanwhile: use that
         else {
-            HIP_TRY(hipSetDevice(g.device));
-            nd->pid = g.pid;
-            nd->dict.id = g.next_dict_id++;
-            const size_t abytes = (size_t)nd->dict.alphabet * sizeof(uint16_t);
-            hipError_t e2 = dev_alloc((void **)&nd->d_left, abytes);
-            if (e2 == hipSuccess) e2 = dev_alloc((void **)&nd->d_right, abytes);
-            if (e2 == hipSuccess) e2 = hipMemcpy(nd->d_left, nd->dict.left.data(), abytes, hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = hipMemcpy(nd->d_right, nd->dict.right.data(), abytes, hipMemcpyHostToDevice);
-            if (e2 == hipSuccess) e2 = dev_alloc((void **)&nd->d_order, std::max<size_t>(abytes, 16));
-            if (e2 == hipSuccess && !nd->order.empty())
-                e2 = hipMemcpy(nd->d_order, nd->order.data(), nd->order.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-            if (e2 != hipSuccess) return fail(IMC_ERR_HIP, std::string("dictionary upload: ") + hipGetErrorString(e2));
+            if (int rc = upload_dictionary(nd)) return rc;
             g.dicts[nsym] = nd;
             dd = nd;
         }
@@ -378,29 +433,10 @@ int obs_upload(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym
                     std::string("observation upload: ") + hipGetErrorString(e));
     }
     if (zipped) {
-        o->dict = dd;
-        for (int l = 0; l < imc::kNumLevels; ++l) {
-            o->alphabet[l] = enc.alphabet[l];
-            o->ntok[l] = enc.length[l];
-            o->wide[l] = enc.is_wide[l];
-            if (l > 0 && enc.alphabet[l] == enc.alphabet[l - 1]) { o->d_tok[l] = o->d_tok[l - 1]; o->wide[l] = o->wide[l - 1]; o->tok_count[l] = o->tok_count[l - 1]; continue; }
-            if (enc.alphabet[l] <= nsym) { o->d_tok[l] = nullptr; continue; }   // raw stream: use d_sym
-            if (!enc.is_wide[l]) {
-                o->tok_count[l].assign((size_t)enc.alphabet[l], 0u);
-                for (size_t t = 1; t < enc.length[l]; ++t) o->tok_count[l][enc.bytes[l][t]]++;   // (position 0 is a raw symbol)
-            } else if (enc.alphabet[l] <= HYBRID_MAX_ALPHABET) {
-                o->tok_count[l].assign((size_t)enc.alphabet[l], 0u);
-                for (size_t t = 1; t < enc.length[l]; ++t) o->tok_count[l][enc.wide[l][t]]++;
-            }
-            hipError_t e3 = enc.is_wide[l]
-                ? upload_padded(reinterpret_cast<const uint8_t *>(enc.wide[l].data()), enc.length[l] * sizeof(imc::tok_t), &o->d_tok[l])
-                : upload_padded(enc.bytes[l].data(), enc.length[l], &o->d_tok[l]);
-            if (e3 != hipSuccess) {
-                obs_release(o);
-                delete o;
-                return fail(e3 == hipErrorOutOfMemory ? IMC_ERR_OOM : IMC_ERR_HIP,
-                            std::string("token stream upload: ") + hipGetErrorString(e3));
-            }
+        if (int rc = install_encoding(o, dd, enc)) {
+            obs_release(o);
+            delete o;
+            return rc;
         }
     }
     *out = o;
@@ -1906,6 +1942,85 @@ int imc_obs_tokens(const imc_obs *obs, int alphabet_limit, uint16_t *tokens, siz
         std::vector<uint8_t> tmp(n);
         if (n) HIP_TRY(hipMemcpy(tmp.data(), src, n, hipMemcpyDeviceToHost));
         for (size_t t = 0; t < n; ++t) tokens[t] = tmp[t];
+    }
+    return IMC_OK;
+}
+
+// Joint re-compression (see the header).  The first sufficiently long chunk of an alphabet trains the dictionary that
+// every later chunk shares; when a data set arrives as many chunks, that sample is one chunk.  Here a new dictionary
+// is trained on a sample drawn evenly from ALL the given chunks and they are re-encoded with it.
+int imc_obs_recompress(imc_obs *const *chunks, int n_chunks)
+{
+    if (n_chunks < 0 || (n_chunks > 0 && !chunks)) return fail(IMC_ERR_ARG, "chunks is null");
+    std::map<int, std::vector<imc_obs *>> by_alphabet;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (int rc = ensure_ctx()) return rc;
+        if (!g.compression) return IMC_OK;
+        for (int f = 0; f < n_chunks; ++f) {
+            imc_obs *o = chunks[f];
+            if (!o) return fail(IMC_ERR_ARG, "chunk is null");
+            if (o->pid != g.pid) return fail(IMC_ERR_HIP, "chunk was created in another process");
+            if (o->L >= ZIP_MIN_COLUMNS && o->nsym < imc::kMaxAlphabet / 2) by_alphabet[o->nsym].push_back(o);
+        }
+    }
+    for (auto &kv : by_alphabet) {
+        const int nsym = kv.first;
+        std::vector<imc_obs *> &obs = kv.second;
+        std::sort(obs.begin(), obs.end());
+        obs.erase(std::unique(obs.begin(), obs.end()), obs.end());
+        const bool wide_raw = nsym > imc::kByteAlphabet;
+        const size_t unit = wide_raw ? sizeof(imc::tok_t) : 1;
+        size_t total = 0;
+        for (imc_obs *o : obs) total += o->L;
+        if (total < DICT_TRAIN_MIN) continue;
+        // ---- raw symbols back to the host (the chunks keep them on the device) ----
+        std::vector<std::vector<uint8_t>> raw(obs.size());
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            HIP_TRY(hipSetDevice(g.device));
+            for (size_t k = 0; k < obs.size(); ++k) {
+                raw[k].resize(obs[k]->L * unit);
+                HIP_TRY(hipMemcpy(raw[k].data(), obs[k]->d_sym, raw[k].size(), hipMemcpyDeviceToHost));
+            }
+        }
+        // ---- training sample: an equal share of every chunk (its head), up to the training budget ----
+        const size_t budget = wide_raw ? DICT_WIDE_TRAIN_TOKENS * 8 : std::max(DICT_TRAIN_MAX, DICT_WIDE_TRAIN_TOKENS * 96);
+        const size_t share = std::max<size_t>(DICT_TRAIN_MIN, budget / obs.size());
+        std::vector<uint8_t> sample;
+        for (size_t k = 0; k < obs.size(); ++k) {
+            const size_t n = std::min(obs[k]->L, share);
+            sample.insert(sample.end(), raw[k].begin(), raw[k].begin() + n * unit);
+        }
+        const size_t ns = sample.size() / unit;
+        auto nd = wide_raw ? make_dictionary(nullptr, reinterpret_cast<const imc::tok_t *>(sample.data()), ns, nsym)
+                           : make_dictionary(sample.data(), nullptr, ns, nsym);
+        std::vector<uint8_t>().swap(sample);
+        // ---- re-encode (host, unlocked), then swap the streams in under the lock ----
+        std::vector<imc::EncodedLevels> enc(obs.size());
+        const bool zipped = nd->dict.alphabet > nsym;
+        if (zipped)
+            for (size_t k = 0; k < obs.size(); ++k) {
+                if (wide_raw) imc::encode_levels(nd->dict, nullptr, reinterpret_cast<const imc::tok_t *>(raw[k].data()), obs[k]->L, enc[k]);
+                else imc::encode_levels(nd->dict, raw[k].data(), nullptr, obs[k]->L, enc[k]);
+                std::vector<uint8_t>().swap(raw[k]);
+            }
+        std::lock_guard<std::mutex> lk(g_mu);
+        HIP_TRY(hipSetDevice(g.device));
+        HIP_TRY(hipDeviceSynchronize());                 // nothing of these chunks is in flight any more
+        for (auto it = g_plans.begin(); it != g_plans.end();) {      // plans hold raw pointers into the old streams
+            bool uses = false;
+            for (size_t k = 0; k < (size_t)(*it)->n_chunks; ++k)
+                for (imc_obs *o : obs) uses |= (*it)->key[k] == o->id;
+            if (uses) { (*it)->release(); it = g_plans.erase(it); } else ++it;
+        }
+        if (!zipped) continue;                           // (incompressible sample: keep what the chunks have)
+        if (int rc = upload_dictionary(nd)) return rc;
+        g.dicts[nsym] = nd;                              // later chunks of this alphabet share it too
+        for (size_t k = 0; k < obs.size(); ++k) {
+            release_tokens(obs[k]);
+            if (int rc = install_encoding(obs[k], nd, enc[k])) return rc;
+        }
     }
     return IMC_OK;
 }

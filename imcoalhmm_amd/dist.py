@@ -48,7 +48,7 @@ class DistributedLikelihood(object):
     """
 
     def __init__(self, model, local_forwarders, group=None, device=None, local_eval=None, reduce_on_host=False,
-                 reduction="allreduce"):
+                 reduction="allreduce", recompress=True):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -73,6 +73,8 @@ class DistributedLikelihood(object):
         # host memory (no device tensor, no reduction kernel, no device-to-host copy through torch)
         self._direct = local_eval is None and self.world_size == 1 and not reduce_on_host
         self._harr = None
+        if recompress and local_eval is None:   # this rank's shard: one pair dictionary trained on all of its chunks
+            hmm.recompress(self.forwarders)
 
     def _hip_eval(self, pis, Ts, Es):
         torch = self._torch

@@ -62,6 +62,17 @@ def forward_chunks_batch(handles, pis, Ts, Es, per_chunk=False):
     return out
 
 
+def recompress(forwarders):
+    """Retrain the shared pair dictionary on ALL the given Forwarders' alignments and re-encode them with it
+    (``imc_obs_recompress``): the counterpart of ziphmm's per-file preprocessing (hmm.py:16) for a data set that comes as
+    many chunks - the dictionary the first chunk alone trained is small.  One-time cost, results change by
+    re-association only.  No-op for fewer than two Forwarders."""
+    ours = [f for f in forwarders if isinstance(f, Forwarder)]
+    if len(ours) < 2:
+        return
+    _capi.check(_capi.lib().imc_obs_recompress(_capi.handle_array([f.handle for f in ours]), len(ours)))
+
+
 def forward_states(handles, pis, Ts, Es, as_operator):
     """State of every chunk instead of its log-likelihood (``imc_forward_state``).
 

@@ -31,12 +31,14 @@ def build_hmms(model, thetas):
 class Likelihood(object):
     """Combining model and data (likelihood.py:8-33)."""
 
-    def __init__(self, model, forwarders):
+    def __init__(self, model, forwarders, recompress=True):
         self.model = model
         if hasattr(forwarders, '__iter__'):
             self.forwarders = list(forwarders)
         else:
             self.forwarders = [forwarders]
+        if recompress:      # several chunks: one pair dictionary trained on all of them (hmm.recompress)
+            hmm.recompress(self.forwarders)
 
     def _split(self):
         ours = [f for f in self.forwarders if isinstance(f, hmm.Forwarder)]

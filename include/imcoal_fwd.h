@@ -81,6 +81,17 @@ int imc_obs_nsym(const imc_obs *obs);
  * dictionary level whose alphabet is <= alphabet_limit; *alphabet_used gets that alphabet
  * (`new_nsyms`).  Returns the raw length when the chunk is not compressed. */
 size_t imc_obs_compressed_length(const imc_obs *obs, int alphabet_limit, int *alphabet_used);
+/* Joint re-compression of a data set that arrived as several chunks.  The pair dictionary of an alphabet is trained
+ * by the first sufficiently long chunk created and shared by every later one (one operator table per evaluation for
+ * all of them); with many chunks - 256 x 1e6 columns in BASELINE config[4] - that training sample is a single chunk
+ * and the dictionary stays small (62 columns per token there, against 110+ from a 3e7-column sample).  This call
+ * trains a new dictionary on a sample drawn evenly from all the given chunks, re-encodes them with it and makes it
+ * the alphabet's dictionary for chunks created later.  Results change by re-association only.  Cached plans of the
+ * chunks are dropped; the call synchronises the device.  Chunks too short to compress are left alone.  The
+ * counterpart in the reference is ziphmm's per-Forwarder preprocessing (hmm.py:16), which compresses every file on
+ * its own; imcoalhmm_amd.Likelihood calls this once for its forwarders. */
+int imc_obs_recompress(imc_obs *const *chunks, int n_chunks);
+
 /* The other two results of ziphmm.preprocess_raw_observations (hmm.py:16), at the deepest dictionary level whose
  * alphabet is <= alphabet_limit:  imc_obs_dictionary = `sym2pair` (token nsym + k is left[k] followed by right[k];
  * call with left = right = NULL to get *alphabet_used first), imc_obs_tokens = `new_obs` (copied back from the
