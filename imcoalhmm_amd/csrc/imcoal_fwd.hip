@@ -132,6 +132,7 @@ struct Ctx {
                               // IMC_BLOCKED=2|3|4|5 at start-up
     int z4_stream = -1;       // k_zpropagate4's table: -1 = streamed (nothing cached in LDS) while the launch's tables are
                               // cache resident, 0 = always the hybrid LDS cache, 1 = always streamed (IMC_Z4_STREAM)
+    bool pack_table = true;   // IMC_PACK_TABLE=0: the mat-vec chain reads the padded table (A/B measurements)
     bool guard = false;       // IMC_GUARD=1: every device buffer ends flush against an unmapped guard range (dev_alloc)
     bool use_graphs = false;  // IMC_GRAPH=1: replay each plan's launch sequence as a hipGraph (measured: no gain, the
                               // per-evaluation latency is kernel time + kernel boundaries, not host launch cost)
@@ -176,6 +177,7 @@ int ensure_ctx()
     if (const char *gd = std::getenv("IMC_GUARD")) g.guard = std::atoi(gd) != 0;
     if (const char *bv = std::getenv("IMC_BLOCKED")) { const int v = std::atoi(bv); if (v >= 2 && v <= 5) g.blocked_variant = v; }
     if (const char *r1 = std::getenv("IMC_RANK1")) g.rank1_handoff = std::atoi(r1) != 0;
+    if (const char *pt = std::getenv("IMC_PACK_TABLE")) g.pack_table = std::atoi(pt) != 0;
     if (const char *zs = std::getenv("IMC_Z4_STREAM")) { const int v = std::atoi(zs); if (v >= -1 && v <= 1) g.z4_stream = v; }
     g.pid = me;
     g.ready = true;
@@ -581,6 +583,7 @@ struct Group {             // one propagate launch
     std::vector<int> tab_lvl;                 // host copy of the depth offsets
     int tab_nlvl = 0;
     double *d_Ctab = nullptr;
+    double *d_Cpack = nullptr;                // big groups that run the mat-vec chain: packed copy of the table ([B][A][N][TS])
     int *d_cex = nullptr;
     // rank-one hand-off (GEMM chain only): operator segments run on the GEMM chain in rounds that end at the
     // checkpoints (token counts); after each round k_rank1_check tests the segments still on the chain, and those
@@ -655,7 +658,7 @@ struct Plan {
         if (graph) (void)hipGraphExecDestroy(graph);
         dev_free(d_segs); dev_free(d_vecs); dev_free(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
+        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_Cpack); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
         dev_free(d_params); dev_free(d_out);
         for (int k = 0; k < 2; ++k) { (void)hipHostFree(h_params[k]); if (ev_params[k]) (void)hipEventDestroy(ev_params[k]); }
         (void)hipHostFree(h_out);
@@ -1247,6 +1250,8 @@ struct PlanBuilder {
             }
             e = up((void **)&gr.d_big_blocks, gr.big_blocks.data(), gr.big_blocks.size() * sizeof(BigBlock));
             if (e == hipSuccess) e = dev_alloc((void **)&gr.d_Ctab, (size_t)B * gr.A * np2 * 8);
+            if (e == hipSuccess && (gr.bigvec || gr.rank1) && N < kc->NP && g.pack_table)   // the mat-vec chain reads a packed copy
+                e = dev_alloc((void **)&gr.d_Cpack, (size_t)B * gr.A * N * (size_t)(N + (N & 1)) * 8);
             if (e == hipSuccess) e = dev_alloc((void **)&gr.d_cex, (size_t)B * gr.A * 4 + 16);
             if (gr.rank1) {
                 for (size_t i2 = 0; i2 < gr.seg_ids.size(); ++i2)
@@ -1436,6 +1441,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
             ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex;
+            ba.Cpack = gr.d_Cpack; ba.TS = N + (N & 1);
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
             ba.phase = gr.rank1 ? 1 : 0; ba.t_from = 0; ba.t_to = gr.rank1 ? gr.checkpoints[0] : INT_MAX;
             ba.r1flag = gr.d_r1flag; ba.r1at = gr.d_r1at; ba.r1u = gr.d_r1u;
@@ -1518,7 +1524,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.n_group_segs = (uint32_t)gr.blocks.size(); ba.n_vecs_total = p->n_vecs;
             ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
-            ba.Ctab = nullptr; ba.cex = nullptr;
+            ba.Ctab = nullptr; ba.cex = nullptr; ba.Cpack = nullptr; ba.TS = 0;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
             ba.tab_order = gr.d_tab_order; ba.tab_lvl = gr.d_tab_lvl; ba.tab_nlvl = gr.tab_nlvl;
             ba.hot = gr.d_hot; ba.n_hot = gr.n_hot; ba.tab_desc = gr.d_tab_desc;

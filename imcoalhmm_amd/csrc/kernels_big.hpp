@@ -59,6 +59,11 @@ struct BigArgs {
     const uint16_t *hot;
     int n_hot;
     const int4 *tab_desc;         // k_z4_level: per entry of tab_order {token, left child, right child, 0} (one load instead of three dependent ones)
+    // k_big_vector reads a PACKED copy of the operator table when there is one: [B][A][N][TS], TS = N rounded up to even
+    // (150 x 150 doubles instead of the 160-double rows the GEMM kernels want: the mat-vec chains are bound by these
+    // bytes and a padded row costs them ten cache lines instead of 9.4); written by the table kernels beside Ctab
+    double *Cpack;
+    int TS;
 };
 
 
@@ -231,6 +236,13 @@ __global__ __launch_bounds__(NT * 64) void k_big_table_raw(BigArgs a)
         const int i = idx / NP, j = idx - i * NP;
         Cs[idx] = (i < a.N && j < a.N) ? Etg[(size_t)s * a.PP + i] * Tp[(size_t)j * a.PP + i] : 0.0;
     }
+    if (a.Cpack) {
+        double *Cp = a.Cpack + ((size_t)b * a.A + s) * a.N * a.TS;
+        for (int idx = tid; idx < a.N * a.TS; idx += BIG_THREADS) {
+            const int i = idx / a.TS, j = idx - i * a.TS;
+            Cp[idx] = j < a.N ? Etg[(size_t)s * a.PP + i] * Tp[(size_t)j * a.PP + i] : 0.0;
+        }
+    }
     if (tid == 0) a.cex[(size_t)b * a.A + s] = 0;
 }
 
@@ -254,6 +266,8 @@ __global__ __launch_bounds__(NT * 64) void k_big_table_level(BigArgs a, const ui
         big_gemm<NT>(Ct + (size_t)zr * NP * NP, Ct + (size_t)zl * NP * NP, row0, col0, tid, panels, acc);
         const int e = big_exponent<NT>(acc, smax, 0, tid);
         big_store<NT>(Ct + (size_t)z * NP * NP, row0, col0, lane, acc, e, NP, NP, NP);
+        if (a.Cpack)   // (the padded rows / columns of the product are exact zeros: columns N .. TS-1 get them)
+            big_store<NT>(a.Cpack + ((size_t)b * a.A + z) * a.N * a.TS, row0, col0, lane, acc, e, a.N, a.TS, (size_t)a.TS);
         if (tid == 0) cex[z] = cex[zl] + cex[zr] + e;
     } else {
         // 14-16 wavefronts leave 128 registers per lane: the product is formed in two column halves, stored
@@ -280,8 +294,11 @@ __global__ __launch_bounds__(NT * 64) void k_big_table_level(BigArgs a, const ui
         for (int tc = 0; tc < NT; ++tc)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                double *p = D + (size_t)(row0 + lg + 4 * q) * NP + tc * 16 + lm;
-                *p = ldexp(*p, -e);
+                const int row = row0 + lg + 4 * q, col = tc * 16 + lm;
+                double *p = D + (size_t)row * NP + col;
+                const double v = ldexp(*p, -e);
+                *p = v;
+                if (a.Cpack && row < a.N && col < a.TS) a.Cpack[((size_t)b * a.A + z) * a.N * a.TS + (size_t)row * a.TS + col] = v;
             }
         if (tid == 0) cex[z] = cex[zl] + cex[zr] + e;
     }
@@ -508,7 +525,10 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     const uint8_t *tokp = sd.obs;
     const double *pp = a.params + (size_t)b * a.pstride;
     const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
-    const double *Ct = a.Ctab + (size_t)b * a.A * NP * NP;
+    const bool packed = a.Cpack != nullptr;
+    const int ld = packed ? a.TS : NP;                               // row stride and entry size of the table that is read
+    const size_t esz = packed ? (size_t)a.N * a.TS : (size_t)NP * NP;
+    const double *Ct = packed ? a.Cpack + (size_t)b * a.A * esz : a.Ctab + (size_t)b * a.A * esz;
     const int *cex = a.cex + (size_t)b * a.A;
 
     const size_t r1 = ((size_t)b * a.n_segs + bk.seg) * NP;
@@ -535,7 +555,7 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         const int row = ps * ROWS_PER_PASS + wave * 4 + lg;
-        rowoff[ps] = row * NP + W * lm;
+        rowoff[ps] = row * ld + W * lm;
     }
     // The table is zero beyond N: the padded rows (last pass) and the padded columns (last piece of a row) are not
     // fetched at all - their registers stay 0 - which saves up to 12 % of the streamed bytes (N = 150 in NP = 160).
@@ -563,12 +583,12 @@ __global__ __launch_bounds__(BigVec<NT>::WAVES * 64) void k_big_vector(BigArgs a
     int tok = len > t0 ? seg_token(tokp, wide, t0) : 0;
     int tok_next = len > t0 + 1 ? seg_token(tokp, wide, t0 + 1) : tok;
     if constexpr (BigVec<NT>::PIPELINED) {
-        const double *A = Ct + (size_t)tok * NP * NP;
+        const double *A = Ct + (size_t)tok * esz;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) BV_LOAD(ps, A);
     }
     for (int t = t0; t < len; ++t) {
-        const double *An = Ct + (size_t)(BigVec<NT>::PIPELINED ? tok_next : tok) * NP * NP;
+        const double *An = Ct + (size_t)(BigVec<NT>::PIPELINED ? tok_next : tok) * esz;
         if constexpr (BigVec<NT>::LOAD_AHEAD) {
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) BV_LOAD(ps, An);
