@@ -448,7 +448,7 @@ int obs_upload(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym
 // ---- kernel table ---------------------------------------------------------------------------------
 
 using ChainFn = void (*)(const ChainDesc *, int, const uint32_t *, uint32_t, uint32_t, const double *, const int *,
-                         const int *, uint32_t, double *, int *);
+                         const int *, uint32_t, double *, int *, double *, int);
 
 struct KernelChoice {
     int R, G, NP, VPW, minw;       // R == 0: large-N GEMM-chain path (kernels_big.hpp), NP = 32 * TR
@@ -633,6 +633,7 @@ struct Plan {
     std::vector<Level> levels;       // levels[0] holds the propagate output
     int32_t *d_final_vec = nullptr;  // per chunk: vector index in the last level, -1 for an empty chunk
     uint64_t chain_steps = 0;        // serial depth of the stitch (sum over levels of the longest chain)
+    bool finish_fused = false;       // the last chain level writes the log-likelihoods itself (no k_finish launch)
     double *d_params = nullptr, *d_out = nullptr;
     // pinned staging of the caller's parameters: two slots used alternately, each guarded by an event recorded behind
     // the call that read it, so a call only waits when the call issued two calls earlier is still running
@@ -1142,9 +1143,24 @@ struct PlanBuilder {
             if (done) break;
         }
         final_vec.assign(std::max(n_chunks, 1), -1);
+        bool all_from_chains = hl.size() > 1 && !op_mode && n_chunks > 0;
         for (int f = 0; f < n_chunks; ++f) {
             const HostLevel &last = hl.back();
             if (last.chunk_seg[f + 1] > last.chunk_seg[f]) final_vec[f] = (int32_t)last.vec0[last.chunk_seg[f]];
+            else all_from_chains = false;               // an empty chunk: k_finish writes its 0.0
+        }
+        // every chunk's final vector comes out of a chain of the last level: those chains write the log-likelihoods
+        // themselves and k_finish is not launched
+        p->finish_fused = false;
+        if (all_from_chains) {
+            HostLevel &last = hl.back();
+            std::vector<char> seen((size_t)n_chunks, 0);
+            for (ChainDesc &cd : last.chains)
+                for (int f = 0; f < n_chunks; ++f)
+                    if (cd.first && final_vec[f] == (int32_t)cd.out_vec) { cd.chunk1 = (uint32_t)f + 1; seen[f] = 1; }
+            p->finish_fused = std::all_of(seen.begin(), seen.end(), [](char c) { return c != 0; });
+            if (!p->finish_fused)
+                for (ChainDesc &cd : last.chains) cd.chunk1 = 0;
         }
 
     }
@@ -1606,12 +1622,13 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             HIP_TRY(hipGetLastError());
         }
         const int threads = (int)round_up((size_t)NP, 64);
+        const bool last_level = l + 2 == p->levels.size();
         hipLaunchKernelGGL(kc->chain, dim3(ot.n_chains, (unsigned)B), dim3(threads), 0, stream,
                            ot.d_chains, N, in.d_vec0, in.n_segs, in.n_vecs, in.d_P, in.d_EX, in.d_EMAX,
-                           ot.n_vecs, ot.d_P, ot.d_EX);
+                           ot.n_vecs, ot.d_P, ot.d_EX, (last_level && p->finish_fused) ? out : (double *)nullptr, p->n_chunks);
         HIP_TRY(hipGetLastError());
     }
-    if (p->n_chunks) {
+    if (p->n_chunks && !p->finish_fused) {
         const Level &last = p->levels.back();
         hipLaunchKernelGGL(k_finish, dim3((p->n_chunks + 63) / 64, (unsigned)B), dim3(64), 0, stream,
                            p->d_final_vec, p->n_chunks, N, NP, last.n_vecs, last.d_P, last.d_EX, out);

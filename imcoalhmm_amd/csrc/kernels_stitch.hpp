@@ -15,7 +15,7 @@ struct ChainDesc {
     uint32_t c;                    // basis index when the run does not start its chunk
     uint32_t out_vec;              // output vector index in the next level
     uint32_t first;                // 1: the run starts with its chunk's first segment (a vector)
-    uint32_t pad;
+    uint32_t chunk1;               // last level only: 1 + the chunk whose final vector this chain produces (0: none)
 };
 
 // EMAX[b][seg] = max_c EX[b][vec0(seg)+c]
@@ -42,7 +42,7 @@ template <int NP, int D>
 __global__ __launch_bounds__(((NP + 63) / 64) * 64) void k_chain(
     const ChainDesc *chains, int N,
     const uint32_t *in_vec0, uint32_t in_n_segs, uint32_t in_n_vecs, const double *Pin, const int *EXin, const int *EMin,
-    uint32_t out_n_vecs, double *Pout, int *EXout)
+    uint32_t out_n_vecs, double *Pout, int *EXout, double *fin_out, int n_chunks)
 {
     __shared__ __attribute__((aligned(16))) double w[2][NP];
     // a single-wavefront workgroup needs no s_barrier (LDS is in-order within a wavefront), and a
@@ -167,7 +167,13 @@ __global__ __launch_bounds__(((NP + 63) / 64) * 64) void k_chain(
         double *dst = cd.first ? Pout + gv * NP + i : Pout + (gv - cd.c) * NP + (size_t)i * NP + cd.c;
         *dst = ldexp(a, -e);
     }
-    if (i == 0) EXout[gv] = etot + e;
+    if (i == 0) {
+        EXout[gv] = etot + e;
+        // last level: the chunk's log-likelihood straight from here (what k_finish computes from the stored vector:
+        // the sum of the normalised entries is this sum scaled by the same exact power of two)
+        if (fin_out && cd.chunk1)
+            fin_out[(size_t)b * n_chunks + (cd.chunk1 - 1)] = (double)(etot + e) * 0.693147180559945309417232121458 + log(ldexp(tot, -e));
+    }
 }
 
 // out[b][f] = log-likelihood of chunk f from its single remaining vector (0.0 for an empty chunk).

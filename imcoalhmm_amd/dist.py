@@ -113,10 +113,7 @@ class DistributedLikelihood(object):
         if self._direct:
             if self._harr is None:
                 self._harr = _capi.handle_array([f.handle for f in self.forwarders])
-            out = ctypes.c_double(0.0)
-            _capi.check(_capi.lib().imc_forward(self._harr, len(self.forwarders), pi.shape[0], E.shape[1],
-                                                _capi.dptr(pi), _capi.dptr(T), _capi.dptr(E), ctypes.byref(out)))
-            return out.value
+            return _capi.forward1(self._harr, len(self.forwarders), pi, T, E)
         return float(self.forward_params_batch(pi[None], T[None], E[None])[0])
 
     def __call__(self, *parameters):

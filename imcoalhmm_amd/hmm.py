@@ -13,10 +13,17 @@ import numpy as np
 from . import _capi
 
 
+def _ready(a):
+    return type(a) is np.ndarray and a.dtype == np.float64 and a.flags.c_contiguous
+
+
 def _params(init_probs, trans_probs, emission_probs):
-    pi = _capi.as_f64(np.asarray(init_probs)).reshape(-1)
-    T = _capi.as_f64(np.asarray(trans_probs))
-    E = _capi.as_f64(np.asarray(emission_probs))
+    if _ready(init_probs) and _ready(trans_probs) and _ready(emission_probs) and init_probs.ndim == 1:
+        pi, T, E = init_probs, trans_probs, emission_probs          # (the common case: nothing to convert)
+    else:
+        pi = _capi.as_f64(np.asarray(init_probs)).reshape(-1)
+        T = _capi.as_f64(np.asarray(trans_probs))
+        E = _capi.as_f64(np.asarray(emission_probs))
     n = pi.shape[0]
     if T.shape != (n, n):
         raise ValueError("trans_probs must be (%d,%d), got %r" % (n, n, T.shape))
@@ -40,10 +47,8 @@ def _batch_params(pis, Ts, Es):
 def forward_chunks(handles, pi, T, E):
     """Sum of chunk log-likelihoods for one parameter set (likelihood.py:33)."""
     pi, T, E = _params(pi, T, E)
-    out = ctypes.c_double(0.0)
-    _capi.check(_capi.lib().imc_forward(_capi.handle_array(handles), len(handles), pi.shape[0], E.shape[1],
-                                        _capi.dptr(pi), _capi.dptr(T), _capi.dptr(E), ctypes.byref(out)))
-    return out.value
+    harr = handles if isinstance(handles, ctypes.Array) else _capi.handle_array(handles)
+    return _capi.forward1(harr, len(handles), pi, T, E)
 
 
 def forward_chunks_batch(handles, pis, Ts, Es, per_chunk=False):
