@@ -79,6 +79,10 @@ constexpr size_t ZIP_MIN_COLUMNS = 4096;           // shorter chunks are not wor
 constexpr size_t DICT_TRAIN_MIN = 32768;           // first chunk at least this long trains the dictionary
 constexpr size_t DICT_TRAIN_MAX = 8u << 20;        // byte tokens (< 256): train on at most this prefix
 constexpr size_t DICT_WIDE_TRAIN_TOKENS = 1u << 19; // 16-bit tokens: train on at most this many byte-level tokens (~4e7 columns)
+constexpr int DICT_MAX_DEPTH = 0;                  // 0: no limit on a token's depth in the dictionary.  (IMC_DICT_MAX_DEPTH, experiments:
+                                                   // the table is built one depth per launch, but the bench alignment's 4096 tokens USE
+                                                   // their 11 depths - a cap of 10 saves one launch at 149.5 instead of 150.2 columns per
+                                                   // token, 9 already costs 13 % of the compression, 8 leaves 208 tokens)
 constexpr size_t DICT_WIDE_MIN_COUNT = 6;          // ... in which a pair must occur this often
 constexpr size_t CTAB_BUDGET = (size_t)24 << 30;   // largest operator table (all parameter sets) a plan may allocate
 #ifndef IMC_HYBRID_MAX_ALPHABET
@@ -309,18 +313,19 @@ size_t wide_min_count(size_t sample_tokens)
 std::shared_ptr<DictDev> make_dictionary(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym)
 {
     auto nd = std::make_shared<DictDev>();
+    const int max_depth = std::getenv("IMC_DICT_MAX_DEPTH") ? std::atoi(std::getenv("IMC_DICT_MAX_DEPTH")) : DICT_MAX_DEPTH;
     if (host16) {                                    // symbols are not bytes: straight to the 16-bit rounds on the raw stream
         imc::init_dict(nd->dict, nsym);
         const size_t nt = std::min(L - 1, DICT_WIDE_TRAIN_TOKENS * 8);
-        imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(host16 + 1, host16 + 1 + nt), DICT_WIDE_MIN_COUNT);
+        imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(host16 + 1, host16 + 1 + nt), DICT_WIDE_MIN_COUNT, max_depth);
     } else {
         const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
-        imc::train_dict(nd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64);
+        imc::train_dict(nd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64, max_depth);
         if (nd->dict.alphabet >= imc::kByteAlphabet) {   // 16-bit tokens: rounds over the whole chunk's byte-level stream
             const size_t cols = std::min(L, DICT_WIDE_TRAIN_TOKENS * 96);   // a byte-level token covers ~60-100 columns
             const std::vector<uint8_t> lvl256 = imc::encode_bytes(nd->dict, host, cols, nullptr);
             const size_t nt = std::min(lvl256.size() - 1, DICT_WIDE_TRAIN_TOKENS);
-            imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), wide_min_count(nt));
+            imc::train_dict_wide(nd->dict, std::vector<imc::tok_t>(lvl256.begin() + 1, lvl256.begin() + 1 + nt), wide_min_count(nt), max_depth);
         }
     }
     nd->depth.assign(nd->dict.alphabet, 0);
@@ -1704,7 +1709,6 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
 {
     std::lock_guard<std::mutex> lk(g_mu);
     static const bool dbg_host = std::getenv("IMC_DEBUG_HOST") != nullptr;     // diagnostics: host time per phase
-    static const int ab_sync = std::getenv("IMC_AB_SYNC") ? std::atoi(std::getenv("IMC_AB_SYNC")) : 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     const auto h0 = now();
     if (int rc = ensure_ctx()) return rc;
@@ -1738,7 +1742,7 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
     for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
     g.last_kernels = p->kernels;
     const auto h3 = now();
-    if (ab_sync == 1 || !n_out) HIP_TRY(hipStreamSynchronize(g.stream));
+    if (!n_out) HIP_TRY(hipStreamSynchronize(g.stream));
     else HIP_TRY(wait_results(g.stream, p->h_out, n_out));
     const auto h4 = now();
     collect_rank1_stats(p);

@@ -102,13 +102,23 @@ inline size_t replace_round(tok_t *seq, size_t n, const std::vector<uint32_t> &k
 
 // Phase 1: train the first merges (alphabet <= kByteAlphabet) on `seq`, a scratch copy of (a prefix of)
 // the chunk without its first column.  Stops when the best pair occurs fewer than `min_count` times.
-inline void train_dict(PairDict &d, int nsym, std::vector<uint8_t> seq, size_t min_count)
+// max_depth > 0: a pair is only merged while its token's depth in the dictionary DAG (1 + the deeper child's) stays
+// within it - the operator table is built one depth per launch, and the last depths hold a handful of very long tokens.
+inline std::vector<int> dict_depths(const PairDict &d)
+{
+    std::vector<int> depth((size_t)d.alphabet, 0);
+    for (int z = d.nsym; z < d.alphabet; ++z) depth[z] = 1 + std::max(depth[d.left[z]], depth[d.right[z]]);
+    return depth;
+}
+
+inline void train_dict(PairDict &d, int nsym, std::vector<uint8_t> seq, size_t min_count, int max_depth = 0)
 {
     d.nsym = nsym;
     d.alphabet = nsym;
     d.left.assign(nsym, 0);
     d.right.assign(nsym, 0);
     d.span.assign(nsym, 1);
+    std::vector<int> depth((size_t)nsym, 0);
     size_t n = seq.size();
     std::vector<uint64_t> count((size_t)kByteAlphabet * kByteAlphabet);
     while (d.alphabet < kByteAlphabet && n >= 2) {
@@ -120,10 +130,13 @@ inline void train_dict(PairDict &d, int nsym, std::vector<uint8_t> seq, size_t m
         int ba = -1, bb = -1;
         for (int a = 0; a < A; ++a)
             for (int b = 0; b < A; ++b)
-                if (count[(size_t)a * A + b] > best) { best = count[(size_t)a * A + b]; ba = a; bb = b; }
+                if (count[(size_t)a * A + b] > best && (max_depth <= 0 || std::max(depth[a], depth[b]) < max_depth)) {
+                    best = count[(size_t)a * A + b]; ba = a; bb = b;
+                }
         if (ba < 0 || best < min_count) break;
         const int z = d.alphabet;
         d.add(ba, bb);
+        depth.push_back(1 + std::max(depth[ba], depth[bb]));
         n = replace_pair<uint8_t>(seq.data(), n, (uint8_t)ba, (uint8_t)bb, (uint8_t)z);
     }
 }
@@ -156,9 +169,10 @@ inline void init_dict(PairDict &d, int nsym)
 // Phase 2: extend a full byte dictionary (or the bare raw alphabet when that has more than 256 symbols) in rounds on
 // `seq`, the byte-level token stream (raw stream) of the training chunk, first column removed.  A pair needs
 // `min_count` occurrences to become a token.
-inline void train_dict_wide(PairDict &d, std::vector<tok_t> seq, size_t min_count)
+inline void train_dict_wide(PairDict &d, std::vector<tok_t> seq, size_t min_count, int max_depth = 0)
 {
     if (d.alphabet < wide_base(d.nsym)) return;
+    std::vector<int> depth = dict_depths(d);
     size_t n = seq.size();
     std::vector<uint32_t> keys, scratch;
     while (d.alphabet < kMaxAlphabet && n >= 2) {
@@ -170,7 +184,8 @@ inline void train_dict_wide(PairDict &d, std::vector<tok_t> seq, size_t min_coun
         for (size_t i = 0; i < keys.size();) {
             size_t j = i;
             while (j < keys.size() && keys[j] == keys[i]) ++j;
-            if (j - i >= min_count) cand.push_back({(uint64_t)(j - i), keys[i]});
+            if (j - i >= min_count && (max_depth <= 0 || std::max(depth[keys[i] >> 16], depth[keys[i] & 0xffffu]) < max_depth))
+                cand.push_back({(uint64_t)(j - i), keys[i]});
             i = j;
         }
         if (cand.empty()) break;
@@ -185,6 +200,7 @@ inline void train_dict_wide(PairDict &d, std::vector<tok_t> seq, size_t min_coun
             rk.push_back(cand[q].second);
             ri.push_back((tok_t)d.alphabet);
             d.add((int)(cand[q].second >> 16), (int)(cand[q].second & 0xffffu));
+            depth.push_back(1 + std::max(depth[cand[q].second >> 16], depth[cand[q].second & 0xffffu]));
         }
         n = replace_round(seq.data(), n, rk, ri);
         if (take < round) break;   // a short round is the last one, so that round boundaries stay where round_size puts them
