@@ -89,7 +89,8 @@ size_t imc_obs_compressed_length(const imc_obs *obs, int alphabet_limit, int *al
  * the alphabet's dictionary for chunks created later.  Results change by re-association only.  Cached plans of the
  * chunks are dropped; the call synchronises the device.  Chunks too short to compress are left alone.  The
  * counterpart in the reference is ziphmm's per-Forwarder preprocessing (hmm.py:16), which compresses every file on
- * its own; imcoalhmm_amd.Likelihood calls this once for its forwarders. */
+ * its own; imcoalhmm_amd.Likelihood calls this once for its forwarders.  The chunks must stay alive for the duration
+ * of the call (do not free them from another thread meanwhile); evaluations on other threads simply wait. */
 int imc_obs_recompress(imc_obs *const *chunks, int n_chunks);
 
 /* The other two results of ziphmm.preprocess_raw_observations (hmm.py:16), at the deepest dictionary level whose
