@@ -5,6 +5,7 @@ compute call raises.  (The CPU oracle under oracle/ is test infrastructure and i
 from here.)
 """
 import ctypes
+import threading
 import os
 
 import numpy as np
@@ -115,24 +116,27 @@ def check(rc):
 
 
 _fwd1 = None
-_out1 = None
+_tls = threading.local()           # one output slot per thread: the library call releases the GIL
 
 
 def forward1(harr, n_chunks, pi, T, E):
     """``imc_forward`` for float64 C-contiguous arrays, with as little Python in front of the call as ctypes allows
     (raw addresses instead of typed pointer objects, one reused output slot): an evaluation of BASELINE config[1] takes
     0.3 ms, and the generic wrapper spent 25 us of that."""
-    global _fwd1, _out1
+    global _fwd1
     if _fwd1 is None:
         proto = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
         _fwd1 = proto(("imc_forward", lib()))
-        _out1 = np.zeros(1, dtype=np.float64)
+    out = getattr(_tls, "out", None)
+    if out is None:
+        out = _tls.out = np.zeros(1, dtype=np.float64)
+        _tls.addr = out.ctypes.data
     rc = _fwd1(ctypes.addressof(harr), n_chunks, pi.shape[0], E.shape[1], pi.ctypes.data, T.ctypes.data, E.ctypes.data,
-               _out1.ctypes.data)
+               _tls.addr)
     if rc != IMC_OK:
         check(rc)
-    return float(_out1[0])
+    return float(out[0])
 
 
 def as_f64(a, shape=None):
