@@ -136,6 +136,7 @@ struct Ctx {
                               // IMC_BLOCKED=2|3|4|5 at start-up
     int z4_stream = -1;       // k_zpropagate4's table: -1 = streamed (nothing cached in LDS) while the launch's tables are
                               // cache resident, 0 = always the hybrid LDS cache, 1 = always streamed (IMC_Z4_STREAM)
+    bool table_pairs = true;  // IMC_TABLE_PAIRS=0: k_zpropagate4's table one dictionary depth per launch (A/B measurements)
     bool pack_table = true;   // IMC_PACK_TABLE=0: the mat-vec chain reads the padded table (A/B measurements)
     bool guard = false;       // IMC_GUARD=1: every device buffer ends flush against an unmapped guard range (dev_alloc)
     bool use_graphs = false;  // IMC_GRAPH=1: replay each plan's launch sequence as a hipGraph (measured: no gain, the
@@ -182,6 +183,7 @@ int ensure_ctx()
     if (const char *bv = std::getenv("IMC_BLOCKED")) { const int v = std::atoi(bv); if (v >= 2 && v <= 5) g.blocked_variant = v; }
     if (const char *r1 = std::getenv("IMC_RANK1")) g.rank1_handoff = std::atoi(r1) != 0;
     if (const char *pt = std::getenv("IMC_PACK_TABLE")) g.pack_table = std::atoi(pt) != 0;
+    if (const char *tp = std::getenv("IMC_TABLE_PAIRS")) g.table_pairs = std::atoi(tp) != 0;
     if (const char *zs = std::getenv("IMC_Z4_STREAM")) { const int v = std::atoi(zs); if (v >= -1 && v <= 1) g.z4_stream = v; }
     g.pid = me;
     g.ready = true;
@@ -483,6 +485,7 @@ struct KernelChoice {
     void (*zip4s)(BigArgs) = nullptr, (*zip4sw)(BigArgs) = nullptr;   // ... with the STREAMED table (nothing cached in LDS)
     void (*zip4_raw)(BigArgs) = nullptr;
     void (*zip4_level)(BigArgs, int, int) = nullptr;
+    void (*zip4_level2)(BigArgs, const int4 *, int, int) = nullptr;   // two dictionary depths per launch
     size_t (*zip4_lds)(int, int) = nullptr;
     int (*zip4_max_hot)(int, size_t) = nullptr;
     int tok_doubles = 0;               // doubles per table entry of the MFMA kernels
@@ -513,6 +516,7 @@ KernelChoice make_kc()
             k.zip4sw = k_zpropagate4<NP / 4, true, false>;
             k.zip4_raw = k_z4_raw<NP / 4>;
             k.zip4_level = k_z4_level<NP / 4>;
+            k.zip4_level2 = k_z4_level2<NP / 4>;
             k.zip4_lds = &Zip4Geom<NP / 4>::lds_bytes;
             k.zip4_max_hot = &Zip4Geom<NP / 4>::max_hot;
         }
@@ -585,6 +589,8 @@ struct Group {             // one propagate launch
     uint16_t *d_tab_order = nullptr;          // blocked MFMA kernel: merged tokens of the alphabet by dictionary depth
     int *d_tab_lvl = nullptr;
     int4 *d_tab_desc = nullptr;               // hybrid table: {token, left, right, 0} per entry of the depth order
+    int4 *d_tab_desc2 = nullptr;              // ... two int4 per entry of the two-depths-per-launch schedule (k_z4_level2)
+    std::vector<std::pair<int, int>> tab2;    // ... (first entry, entries) per launch
     std::vector<int> tab_lvl;                 // host copy of the depth offsets
     int tab_nlvl = 0;
     double *d_Ctab = nullptr;
@@ -664,7 +670,7 @@ struct Plan {
         if (graph) (void)hipGraphExecDestroy(graph);
         dev_free(d_segs); dev_free(d_vecs); dev_free(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_Cpack); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
+        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_desc2); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_Cpack); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
         dev_free(d_params); dev_free(d_out);
         for (int k = 0; k < 2; ++k) { (void)hipHostFree(h_params[k]); if (ev_params[k]) (void)hipEventDestroy(ev_params[k]); }
         (void)hipHostFree(h_out);
@@ -840,7 +846,9 @@ struct PlanBuilder {
                             // from the global table at ~6 % over the LDS-table kernel's step: measured at config[1])
                             const double cold_pen = table_bytes / B <= 3.6e6 ? 0.11 : 0.17;
                             const bool streamed = g.z4_stream == 1 || (g.z4_stream < 0 && table_bytes <= Z4_STREAM_MAX_BYTES);
-                            cost = depths * 4.0 + 8.0 + steps * t_step * (streamed ? 1.06 : 1.0 + cold_pen * cold);
+                            // (table: one ~4.5 us launch per depth, or one ~5.7 us launch per pair of depths)
+                            const double t_table = g.table_pairs ? std::ceil(depths / 2.0) * 5.7 : depths * 4.5;
+                            cost = t_table + 8.0 + steps * t_step * (streamed ? 1.06 : 1.0 + cold_pen * cold);
                         }
                         if (g.blocked_variant == 5 && !fits) cost *= 1e-3;      // tests: the hybrid table wherever it is possible
                         if (cost < best) { best = cost; best_l = l; }
@@ -1245,6 +1253,38 @@ struct PlanBuilder {
                     std::vector<int4> desc;
                     for (uint16_t z : order) desc.push_back(make_int4((int)z, (int)dd.dict.left[z], (int)dd.dict.right[z], 0));
                     e = up((void **)&gr.d_tab_desc, desc.data(), desc.size() * sizeof(int4));
+                    // two depths per launch (k_z4_level2): launch k builds depths 2k+1 and 2k+2; a second-depth token
+                    // whose child sits in the first depth recomputes it from the grandchildren.  Entries of a launch:
+                    // the first depth's, then the second depth's grouped by which children they recompute, every group
+                    // padded to whole wavefronts (four entries) with idle entries (token -1).
+                    std::vector<int4> d2;
+                    gr.tab2.clear();
+                    auto pad4 = [&]() { while ((d2.size() / 2) % 4) { d2.push_back(make_int4(-1, 0, 0, 0)); d2.push_back(make_int4(0, 0, 0, 0)); } };
+                    for (int d = 0; d < gr.tab_nlvl; d += 2) {
+                        const int first = (int)(d2.size() / 2);
+                        for (int k = lvl[d]; k < lvl[d + 1]; ++k) {
+                            const int z = order[k];
+                            d2.push_back(make_int4(z, (int)dd.dict.left[z], (int)dd.dict.right[z], 0));
+                            d2.push_back(make_int4(0, 0, 0, 0));
+                        }
+                        pad4();
+                        if (d + 1 < gr.tab_nlvl) {
+                            const int d_first = dd.depth[order[lvl[d]]];
+                            for (int flags = 1; flags <= 3; ++flags) {
+                                for (int k = lvl[d + 1]; k < lvl[d + 2]; ++k) {
+                                    const int z = order[k], zl = dd.dict.left[z], zr = dd.dict.right[z];
+                                    const bool nl = zl >= S && dd.depth[zl] == d_first, nr = zr >= S && dd.depth[zr] == d_first;
+                                    if ((nl ? 1 : 0) + (nr ? 2 : 0) != flags) continue;
+                                    d2.push_back(make_int4(z, zl, zr, flags));
+                                    d2.push_back(make_int4(nl ? (int)dd.dict.left[zl] : 0, nl ? (int)dd.dict.right[zl] : 0,
+                                                           nr ? (int)dd.dict.left[zr] : 0, nr ? (int)dd.dict.right[zr] : 0));
+                                }
+                                pad4();
+                            }
+                        }
+                        gr.tab2.push_back({first, (int)(d2.size() / 2) - first});
+                    }
+                    if (e == hipSuccess && !d2.empty()) e = up((void **)&gr.d_tab_desc2, d2.data(), d2.size() * sizeof(int4));
                 }
             }
             if (!gr.big || e != hipSuccess) continue;
@@ -1555,6 +1595,13 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                 ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex;
                 hipLaunchKernelGGL(kc->zip4_raw, dim3((unsigned)S + 1, (unsigned)B), dim3(256), 0, stream, ba);
                 HIP_TRY(hipGetLastError());
+                if (g.table_pairs && gr.d_tab_desc2) {
+                    for (const auto &lc : gr.tab2) {          // two dictionary depths per launch
+                        hipLaunchKernelGGL(kc->zip4_level2, dim3((unsigned)(lc.second + 3) / 4, (unsigned)B), dim3(64), 0, stream, ba,
+                                           (const int4 *)gr.d_tab_desc2, lc.first, lc.second);
+                        HIP_TRY(hipGetLastError());
+                    }
+                } else
                 for (int d = 0; d < gr.tab_nlvl; ++d) {   // one launch per dictionary depth: kernel boundaries order the depths
                     const int first = gr.tab_lvl[d], count = gr.tab_lvl[d + 1] - first;
                     hipLaunchKernelGGL(kc->zip4_level, dim3((unsigned)(count + 3) / 4, (unsigned)B), dim3(64), 0, stream, ba, first, count);

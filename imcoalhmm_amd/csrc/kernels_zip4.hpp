@@ -122,6 +122,102 @@ __global__ __launch_bounds__(64) void k_z4_level(BigArgs a, int first, int count
     }
 }
 
+// TWO dictionary depths per launch.  A token of the second depth has at least one child in the first, which a sibling
+// workgroup of the same launch is only just building - so the wavefront RECOMPUTES that child from the grandchildren
+// (both older than the launch), keeps the product in registers (a left child: a result tile is already in the layout
+// of a B operand) or turns it round through LDS (a right child is needed as A operand rows), and goes on to the token
+// itself.  Scaling by powers of two is exact, so the un-normalised recomputed child gives the same bits as the stored,
+// normalised one (the exponents are carried separately).  An entry is two int4: {token, left, right, flags} and the
+// grandchildren {ll, lr, rl, rr}; flags bit 0 / 1: recompute the left / right child; 0: a first-depth token, built as
+// k_z4_level does.  The host sorts a launch's entries so that the four of a wavefront share their flags (padded with
+// idle entries), which keeps the three phases wavefront-uniform; a mixed wavefront is still correct (a child that
+// needs no recomputing is "recomputed" as child x identity, which is exact).
+// Saves a kernel boundary (~4.9 us) per pair of depths for ~1.5-3 us of extra products: 12 -> 7 launches at 4096 tokens.
+template <int NT>
+__global__ __launch_bounds__(64) void k_z4_level2(BigArgs a, const int4 *desc2, int first, int count)
+{
+    using Geo = Zip3Geom<NT>;
+    constexpr int TOK = Geo::TOK;
+    __shared__ __attribute__((aligned(16))) double turn[4 * TOK];          // one entry per MFMA block: D layout in, A rows out
+    const int b = blockIdx.y, lane = threadIdx.x;
+    const int q = lane >> 4, bq = (lane >> 2) & 3, r = lane & 3;
+    const int lo = (q * 4 + r) * Geo::NTE, lx = q * 4 + r;
+    double *Gt = a.Ctab + (size_t)b * (a.A + 1) * TOK;
+    int *Gc = a.cex + (size_t)b * (a.A + 1);
+    const int IDENT = a.A;
+    const int ti = blockIdx.x * 4 + bq;
+    int4 d0 = ti < count ? desc2[2 * (first + ti)] : make_int4(-1, 0, 0, 0);
+    int4 d1 = ti < count ? desc2[2 * (first + ti) + 1] : make_int4(0, 0, 0, 0);
+    const bool have = d0.x >= 0;                                       // (token -1: a padding entry - multiplies identities, stores nothing)
+    if (!have) { d0 = make_int4(IDENT, IDENT, IDENT, 0); d1 = make_int4(IDENT, IDENT, IDENT, IDENT); }
+    const int z = d0.x, zl = d0.y, zr = d0.z;
+    const bool needL = (d0.w & 1) != 0, needR = (d0.w & 2) != 0;
+    const bool anyL = __any(needL), anyR = __any(needR);              // wavefront-uniform
+
+    auto load_B = [&](double (&Bt)[NT][NT], int tok) __attribute__((always_inline)) {
+        const double *G = Gt + (size_t)tok * TOK;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) Bt[K][J] = G[Geo::idx(4 * K + q, 4 * J + r)];
+    };
+    auto load_A = [&](double (&Ar)[NT][NT], int tok) __attribute__((always_inline)) {
+        const double *G = Gt + (size_t)tok * TOK;
+#pragma unroll
+        for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(Ar[I], G, I, lo, lx);
+    };
+
+    // ---- left child as the B operand ----
+    double L[NT][NT];
+    int eL;
+    if (anyL) {
+        const int t0 = needL ? d1.x : zl, t1 = needL ? d1.y : IDENT;      // L = C_t1 * C_t0
+        double Bt[NT][NT], Ar[NT][NT];
+        load_B(Bt, t0);
+        load_A(Ar, t1);
+        eL = Gc[t0] + Gc[t1];
+        zip4_step_regs<NT>(Bt, L, Ar);
+    } else {
+        load_B(L, zl);
+        eL = Gc[zl];
+    }
+    // ---- right child as A operand rows ----
+    double R[NT][NT];
+    int eR;
+    if (anyR) {
+        const int t0 = needR ? d1.z : zr, t1 = needR ? d1.w : IDENT;      // R = C_t1 * C_t0
+        double Bt[NT][NT], Ar[NT][NT], Out[NT][NT];
+        load_B(Bt, t0);
+        load_A(Ar, t1);
+        eR = Gc[t0] + Gc[t1];
+        zip4_step_regs<NT>(Bt, Out, Ar);
+        double *mine = turn + bq * TOK;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) mine[Geo::idx(4 * K + q, 4 * J + r)] = Out[K][J];
+        wave_fence();
+#pragma unroll
+        for (int I = 0; I < NT; ++I) zip3_load_row<NT>(R[I], mine, I, lo, lx);
+    } else {
+        load_A(R, zr);
+        eR = Gc[zr];
+    }
+    // ---- the token itself ----
+    double Out[NT][NT];
+    zip4_step_regs<NT>(L, Out, R);
+    int e2 = 0;
+    zip3_rescale<NT>(Out, e2);
+    if (have) {
+        double *Gz = Gt + (size_t)z * TOK;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) Gz[Geo::idx(4 * K + q, 4 * J + r)] = Out[K][J];
+        if (q == 0 && r == 0) Gc[z] = eL + eR + e2;
+    }
+}
+
 // ---- the scan -----------------------------------------------------------------------------------------------------
 struct Z4Tok {              // one step's operator for this lane's segment (kept small: five of them are live in the loop)
     int s;                  // LDS slot, or -1: not cached in LDS - operands come from the registers loaded from the global table

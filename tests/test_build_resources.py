@@ -8,7 +8,7 @@ import tempfile
 
 from imcoalhmm_amd import build
 
-HOT = ("k_zpropagate4", "k_z4_level", "k_zpropagate3", "k_zpropagate2", "k_zpropagate", "k_propagate", "k_big_propagate", "k_big_vector", "k_chain")
+HOT = ("k_zpropagate4", "k_z4_level", "k_z4_level2", "k_zpropagate3", "k_zpropagate2", "k_zpropagate", "k_propagate", "k_big_propagate", "k_big_vector", "k_chain")
 
 
 def test_hot_kernels_do_not_spill():
