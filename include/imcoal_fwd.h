@@ -35,6 +35,12 @@
  *   IMC_GRAPH=1        replay each plan as a hipGraph (measured: no gain)
  *   IMC_GUARD=1        test facility: every device buffer is its own virtual-memory mapping that ends flush against an
  *                      unmapped range, so any access past a buffer's end faults at once (tests/test_gpu_guard.py)
+ *   IMC_DEBUG_R1=1     print where each operator segment was certified rank one (hand-off checkpoints) to stderr
+ *   IMC_DEBUG_HOST=1   print the host time per phase of the synchronous entry points (plan, stage, enqueue, wait)
+ *   A/B switches for measurements (the default is the faster setting): IMC_TABLE_PAIRS=0 (k_zpropagate4's table one
+ *   dictionary depth per launch instead of two), IMC_PACK_TABLE=0 (the mat-vec chain reads the 16-padded operator
+ *   table), IMC_Z4_STREAM / IMC_BLOCKED / IMC_RANK1 (see the setters below), IMC_DICT_MIN_COUNT=n and
+ *   IMC_DICT_MAX_DEPTH=d (dictionary training: occurrences a pair needs; cap on a token's depth)
  *
  * fork(): a child forked AFTER the parent's first imc_* call gets IMC_ERR_HIP from every call (HIP state does not
  * survive fork and nothing of the parent's is touched); fork chain processes first, or use the spawn start method.
