@@ -192,6 +192,7 @@ def main():
         requests += [("c3", "im150_t0", 100_000_000, 20240002)]
         requests += [("c4_%d" % i, "iso20_t0", 10_000_000, 20240100 + i) for i in range(32)]
         requests += [("c5_%d" % i, "im150_t0", 1_000_000, 20240600 + i) for i in range(32)]
+        requests += [("c5n20_%d" % i, "iso20_t0", 1_000_000, 20240700 + i) for i in range(32)]
     data = generate(requests)
     t_gen = time.time() - t0
 
@@ -441,6 +442,18 @@ def extra_configs(lib, d, data, fence):
     h = [f.handle for f in fw]
     run("initial-migration-model 150 states, 64 proposals/step x 32 x 1000000-column chunks (per-GPU slice of BASELINE config[4])",
         fw, lambda: float(forward_chunks_batch(h, pis, Ts, Es)[0]), 3.2e7, 64, 2, 1)
+    res[-1]["setup_s"] = time.time() - t0
+    res[-1]["model_build_ms_per_hmm"] = ms
+    del fw, h
+    # config[4] as BASELINE.json literally words it for the reference's model sizes: 20 states, same batch shape
+    pis, Ts, Es, ms = proposals(d, "iso20_t0", 20, 64)
+    t0 = time.time()
+    _capi.check(lib.imc_dictionary_reset())
+    fw = [Forwarder.from_array(data.pop("c5n20_%d" % i), 3) for i in range(32)]
+    recompress(fw)
+    h = [f.handle for f in fw]
+    run("isolation-model 20 states, 64 proposals/step x 32 x 1000000-column chunks (BASELINE config[4] shape at 20 states)",
+        fw, lambda: float(forward_chunks_batch(h, pis, Ts, Es)[0]), 3.2e7, 64, 5, 2)
     res[-1]["setup_s"] = time.time() - t0
     res[-1]["model_build_ms_per_hmm"] = ms
     del fw, h
