@@ -109,6 +109,7 @@ struct DictDev {                                   // one trained dictionary + i
     uint16_t *d_order = nullptr;                   // merged tokens sorted by (depth, id)
     std::vector<uint16_t> order;                   // host copy of d_order
     std::vector<int> depth;                        // per token; raw symbols have depth 0
+    uint64_t trained_on = 0;                       // columns of the chunk(s) the training sample was drawn from
     pid_t pid = 0;
     ~DictDev()
     {
@@ -408,6 +409,7 @@ int obs_upload(const uint8_t *host, const imc::tok_t *host16, size_t L, int nsym
     }
     if (train) {                                        // host only, unlocked
         auto nd = make_dictionary(host, host16, L, nsym);
+        nd->trained_on = L;
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g.dicts.find(nsym);
         if (it != g.dicts.end()) dd = it->second;       // another thread published one meanwhile: use that
@@ -2048,6 +2050,13 @@ int imc_obs_recompress(imc_obs *const *chunks, int n_chunks)
         size_t total = 0;
         for (imc_obs *o : obs) total += o->L;
         if (total < DICT_TRAIN_MIN) continue;
+        {   // nothing to gain if these chunks already share a dictionary trained on at least this much data
+            // (a second Likelihood over the same forwarders, a subset of a recompressed set)
+            std::lock_guard<std::mutex> lk(g_mu);
+            bool same = obs[0]->dict != nullptr;
+            for (imc_obs *o : obs) same = same && o->dict == obs[0]->dict;
+            if (same && obs[0]->dict->trained_on >= total) continue;
+        }
         // ---- raw symbols back to the host (the chunks keep them on the device) ----
         std::vector<std::vector<uint8_t>> raw(obs.size());
         {
@@ -2070,6 +2079,7 @@ int imc_obs_recompress(imc_obs *const *chunks, int n_chunks)
         auto nd = wide_raw ? make_dictionary(nullptr, reinterpret_cast<const imc::tok_t *>(sample.data()), ns, nsym)
                            : make_dictionary(sample.data(), nullptr, ns, nsym);
         std::vector<uint8_t>().swap(sample);
+        nd->trained_on = total;
         // ---- re-encode (host, unlocked), then swap the streams in under the lock ----
         std::vector<imc::EncodedLevels> enc(obs.size());
         const bool zipped = nd->dict.alphabet > nsym;

@@ -45,6 +45,8 @@ def test_joint_dictionary_matches_oracle_and_compresses_better(oracle, hmm_param
     class M(object):
         def valid_parameters(self, theta): return True
         def build_hidden_markov_model(self, theta): return pi, T, E
+    ll = Likelihood(M(), fw)                       # same forwarders again: nothing to retrain (same dictionary object)
+    assert fw[0].new_nsyms == late.new_nsyms
     ll = Likelihood(M(), fw + [late])
     want_total = sum(oracle.forward_scaled(pi, T, E, c) for c in chunks) + oracle.forward_scaled(pi, T, E, chunks[1])
     assert rel_err(ll(np.zeros(3)), want_total) < 1e-11
