@@ -14,12 +14,20 @@ int main() {
         std::vector<uint8_t> obs(L);
         for (auto &x : obs) x = (rng() % 100 < (big ? 97 : 80)) ? 0 : rng() % nsym;
         imc::PairDict d;
-        imc::train_dict(d, nsym, std::vector<uint8_t>(obs.begin() + 1, obs.end()), 4);
+        const int max_depth = rep % 3 == 1 ? 3 + rep % 4 : 0;      // every third stream with a cap on the token depth
+        imc::train_dict(d, nsym, std::vector<uint8_t>(obs.begin() + 1, obs.end()), 4, max_depth);
         if (d.alphabet >= imc::kByteAlphabet) {
             const std::vector<uint8_t> b = imc::encode_bytes(d, obs.data(), L, nullptr);
-            imc::train_dict_wide(d, std::vector<imc::tok_t>(b.begin() + 1, b.end()), 3);
+            imc::train_dict_wide(d, std::vector<imc::tok_t>(b.begin() + 1, b.end()), 3, max_depth);
         }
         if ((int)d.left.size() != d.alphabet || (int)d.right.size() != d.alphabet) { std::printf("dictionary size\n"); return 1; }
+        {
+            const std::vector<int> depth = imc::dict_depths(d);
+            for (int z = 0; z < d.alphabet; ++z) {
+                if (z < nsym ? depth[z] != 0 : (depth[z] < 1 || d.left[z] >= z || d.right[z] >= z)) { std::printf("depth / order\n"); return 1; }
+                if (max_depth > 0 && depth[z] > max_depth) { std::printf("depth cap %d exceeded: %d\n", max_depth, depth[z]); return 1; }
+            }
+        }
         imc::EncodedLevels enc;
         imc::encode_levels(d, obs.data(), nullptr, L, enc);
         // decode each level and compare
