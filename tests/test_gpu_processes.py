@@ -209,3 +209,52 @@ def test_device_output_path_is_asynchronous_and_exact(tmp_path):
     script.write_text(DEVICE_PATH)
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-500:], out.stderr[-2000:])
+
+
+AB_SWITCHES = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from imcoalhmm_amd import Forwarder, _capi, synth
+    from imcoalhmm_amd.hmm import forward_chunks_batch
+    L = _capi.lib()
+    out = []
+    # register-blocked MFMA kernel on a global table (two dictionary depths per table launch, or one)
+    _capi.check(L.imc_set_compression(3)); _capi.check(L.imc_set_blocked_kernel(5))
+    for n in (10, 20):
+        hmms = [synth.random_hmm(n, 3, seed=50 + n + b, stay=0.995) for b in range(2)]
+        chunks = [synth.sample_alignment(*hmms[0], m, seed=9 + k) for k, m in enumerate((900_000, 4099, 120_000))]
+        fw = [Forwarder.from_array(c, 3) for c in chunks]
+        v = forward_chunks_batch([f.handle for f in fw], *(np.stack([h[k] for h in hmms]) for k in range(3)), per_chunk=True)
+        assert "k_zpropagate4" in _capi.last_plan()["kernels"]
+        out += [float(x).hex() for x in v.ravel()]
+        _capi.check(L.imc_dictionary_reset())
+    # mat-vec chain at 150 states (packed or padded operator table), and the hand-off tails of a long chunk
+    _capi.check(L.imc_set_compression(1)); _capi.check(L.imc_set_blocked_kernel(4))
+    h150 = synth.random_hmm(150, 3, seed=7, stay=0.5)
+    many = [Forwarder.from_array(synth.sample_alignment(*h150, 6000 + 37 * k, seed=k), 3) for k in range(40)]
+    v = forward_chunks_batch([f.handle for f in many], *(x[None] for x in h150), per_chunk=True)
+    out += [float(x).hex() for x in v.ravel()]
+    out.append(_capi.last_plan()["kernels"])
+    long1 = Forwarder.from_array(synth.sample_alignment(*h150, 1_500_000, seed=3), 3)
+    out.append(float(long1.forward(*h150)).hex())
+    out.append(_capi.last_plan()["kernels"])
+    print(" ".join(out))
+''') % (REPO,)
+
+
+def test_ab_switches_change_nothing_but_the_schedule(tmp_path):
+    """The launch-schedule switches of the header (IMC_TABLE_PAIRS: two dictionary depths per table launch with the
+    second depth's children recomputed; IMC_PACK_TABLE: the mat-vec chain reads a packed copy of the operator table)
+    re-associate nothing: every value must come out bit for bit the same with the switch on and off.  (Own processes:
+    the switches are read when the library's context is created.)"""
+    script = tmp_path / "ab.py"
+    script.write_text(AB_SWITCHES)
+    outs = {}
+    for pairs, pack in ((1, 1), (0, 1), (1, 0)):
+        env = dict(os.environ, IMC_TABLE_PAIRS=str(pairs), IMC_PACK_TABLE=str(pack))
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+        outs[(pairs, pack)] = r.stdout.strip().splitlines()[-1]
+    assert outs[(1, 1)] == outs[(0, 1)] == outs[(1, 0)], outs
+    assert "k_big_vector" in outs[(1, 1)] and "k_big_propagate" in outs[(1, 1)]      # both large-N paths were on the route
