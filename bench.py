@@ -7,8 +7,13 @@ per-step host input is only (pi, T, E) (a few KB), exactly what Forwarder.forwar
 
   --gpus 1 : BASELINE config[1] - isolation model, 20 states, 1 x 100 Mbp synthetic pairwise alignment
              (--workload config4-slice gives the per-GPU slice of the multi-GPU workload on one GPU)
-  --gpus N : BASELINE config[3] sliced per GPU - 32 x 10 Mbp chunks per rank (256 chunks at N=8),
+  --gpus N : BASELINE config[3] sliced per GPU - 32 x 10 Mbp chunks per rank (256 chunks at N=8, weak scaling),
              chunks sharded statically, one RCCL all-reduce(sum) of the partial log-likelihoods per step.
+             The line carries its OWN single-GPU base: before the group run every rank times its shard alone through
+             the same entry point without the collective (`single_gpu_same_workload`, `scaling_efficiency`), and the
+             per-rank step times (`rank_ms_per_step`), so the N>1 lines can be judged without the N=1 line (whose
+             workload, config[1], is a different one).
+             --strong: BASELINE config[3] as worded - 256 chunks in total, 256/N per rank (also valid at N=1).
              Launched by the driver under torch.distributed.run; run directly (no WORLD_SIZE in the
              environment) it starts its own N rank processes before anything touches the GPU.
 
@@ -51,9 +56,9 @@ def parse_args(argv=None):
                     help="parameter sets evaluated per step (BASELINE config[4] uses 64 proposals/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gen-workers", type=int, default=0,
-                    help="processes that sample the synthetic alignments (0 = up to 16, forked before the first GPU call). "
-                         "Use 1 under rocprofv3 --pmc: the profiler initialises the GPU before Python starts, and a fork "
-                         "from a GPU-initialised process can hang")
+                    help="processes that sample the synthetic alignments (0 = automatic: up to 16, forked before the "
+                         "first GPU call - or in-process when a profiler's tool library is injected, because rocprofv3 "
+                         "--pmc initialises the GPU before Python starts and a fork from such a process can hang)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs leg (profiling runs)")
     ap.add_argument("--no-compress", action="store_true",
                     help="raw symbol stream (one step per alignment column), kernel chosen automatically")
@@ -62,6 +67,9 @@ def parse_args(argv=None):
     ap.add_argument("--split-file", action="store_true",
                     help="N>1 only: ONE alignment of --columns (default 1e8) columns cut into contiguous slices, one per "
                          "rank, stitched with exact transfer operators (strong scaling; dist.SplitAlignmentLikelihood)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling of BASELINE config[3]: --chunks (default 256) chunks of --columns (default 1e7) "
+                         "columns in TOTAL, dealt round-robin over the ranks; with --gpus 1 all of them on one GPU")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses device 0 and the reduction runs "
                          "over gloo (RCCL refuses two ranks on one device); never used for reported numbers")
@@ -89,6 +97,17 @@ def _gen_piece(task):
     return synth.sample_alignment(d[key + "_pi"], d[key + "_T"], d[key + "_E"], n, seed=seed)
 
 
+def under_profiler():
+    """True when a GPU profiler / tool library has been injected into this process (rocprofv3 sets these before Python
+    starts, and with --pmc its library has initialised the GPU by then): no fork pool in that case."""
+    env = os.environ
+    if any(env.get(k) for k in ("HSA_TOOLS_LIB", "ROCP_TOOL_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")):
+        return True
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCTRACER_")) for k in env):
+        return True
+    return any(t in env.get("LD_PRELOAD", "") for t in ("rocprof", "roctracer", "rocprofiler"))
+
+
 def generate(requests):
     """requests: list of (tag, fixture key, columns, seed) -> {tag: uint8 array}.  Pieces of <= 1e7 columns are sampled
     in a fork pool - this runs BEFORE the first library / HIP call of the process, so the children inherit no GPU state."""
@@ -98,6 +117,8 @@ def generate(requests):
             tasks.append((key, min(PIECE, cols - off), seed * 1000 + k))
             index.append(tag)
     workers = max(1, min(len(tasks), os.cpu_count() or 1, 16, GEN_WORKERS or 16))
+    if not GEN_WORKERS and under_profiler():
+        workers = 1            # the GPU is already initialised in this process: a forked child can hang
     if workers > 1:
         import multiprocessing as mp
         with mp.get_context("fork").Pool(workers) as pool:
@@ -160,7 +181,9 @@ def main():
     pi, T, E = d[key + "_pi"], d[key + "_T"], d[key + "_E"]
     n_states = pi.shape[0]
     model_name = "isolation-model" if key.startswith("iso") else "initial-migration-model"
-    workload_kind = args.workload if args.workload != "auto" else ("config2" if world == 1 else "config4-slice")
+    workload_kind = args.workload if args.workload != "auto" else ("config2" if world == 1 and not args.strong else "config4-slice")
+    if args.strong and (args.split_file or workload_kind == "config2"):
+        raise SystemExit("--strong shards the chunks of BASELINE config[3]; it does not combine with --split-file / config2")
 
     from imcoalhmm_amd.dist import shard_indices, slice_bounds
     split = world > 1 and args.split_file
@@ -176,6 +199,13 @@ def main():
         seeds = [20240001 + (1 if not key.startswith("iso") else 0) + k for k in range(chunks_per_rank)]
         if world > 1:
             raise SystemExit("--workload config2 is a single-GPU workload (use --split-file to cut one alignment over ranks)")
+    elif args.strong:
+        total_chunks, cols = args.chunks or 256, args.columns or 10_000_000
+        mine = shard_indices(total_chunks, rank, world)
+        chunks_per_rank = len(mine)
+        workload = "%s %d states, %d x %d-column synthetic chunks in total, sharded over %d GPU%s (BASELINE config[3], strong scaling)" % (
+            model_name, n_states, total_chunks, cols, world, "" if world == 1 else "s")
+        seeds = [20240100 + i for i in mine]
     else:
         chunks_per_rank, cols = args.chunks or 32, args.columns or 10_000_000
         workload = "%s %d states, %d x %d-column synthetic chunks sharded over %d GPU%s (BASELINE config[3] slice)" % (
@@ -193,6 +223,7 @@ def main():
         requests += [("c4_%d" % i, "iso20_t0", 10_000_000, 20240100 + i) for i in range(32)]
         requests += [("c5_%d" % i, "im150_t0", 1_000_000, 20240600 + i) for i in range(32)]
         requests += [("c5n20_%d" % i, "iso20_t0", 1_000_000, 20240700 + i) for i in range(32)]
+        requests += [("a10_%d" % i, "iso10_t0", 1_000_000, 20240800 + i) for i in range(100)]
     data = generate(requests)
     t_gen = time.time() - t0
 
@@ -255,6 +286,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: first every rank times its own shard ALONE - the same entry point (device output on torch's stream, read
+    # back) without the collective, all ranks at once, each on its own GPU - which is the line's single-GPU base
+    alone_elapsed = None
+    if world > 1 and not split:
+        def step_alone():
+            if args.batch > 1:
+                return float(ll.forward_params_batch(pis, Ts, Es, reduce=False)[0])
+            return ll.forward_params(pi, T, E, reduce=False)
+        _, alone_elapsed, _, _ = timed_steps(lib, step_alone, args.steps, args.warmup, torch.cuda.synchronize)
     value, elapsed, k_ms, s_ms = timed_steps(lib, step, args.steps, args.warmup, fence)
     plan = _capi.last_plan()
     rank1_stats = None
@@ -265,15 +305,12 @@ def main():
     ntok0, alpha0 = forwarders[0].compressed_length(plan["token_alphabet"] or 256) if plan["vector_tokens"] else (len(forwarders[0]), 3)
 
     ranks = 1
+    scaling_fields = {}
     if world > 1:
         ranks = dist.get_world_size()
         rdev = torch.device("cpu") if args.rehearse_on_one_gpu else dev
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor([float(local_cols)], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_cols = float(tot.item())
+        elapsed, total_cols, scaling_fields = scaling_report(torch, dist, rdev, elapsed, alone_elapsed, float(local_cols),
+                                                             args.batch, args.steps)
     else:
         total_cols = float(local_cols)
 
@@ -312,7 +349,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if split else "weak",
+            "scaling": "strong" if (split or args.strong) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -344,6 +381,7 @@ def main():
                 },
             },
         }
+        out.update(scaling_fields)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pi, T, E, first_chunk, args.cpu_sample_columns)
     if extras:
@@ -356,6 +394,39 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def scaling_report(torch, dist, rdev, elapsed, alone_elapsed, local_cols, batch, steps):
+    """Collective part of an N > 1 line: (max-over-ranks elapsed, total columns, fields for the JSON line).
+
+    `rank_ms_per_step`: every rank's own step time in the group run (a straggler shows as max >> min).
+    `single_gpu_same_workload`: the ranks' shards timed alone (no collective) - value = the slowest rank's columns/s on
+    its own shard; `scaling_efficiency` = group value / (sum over ranks of their alone values), i.e. what the collective
+    and rank skew cost relative to N independent GPUs on this same workload (weak scaling: the driver's own curve
+    should be read against THIS base, not against the N=1 line, which measures BASELINE config[1])."""
+    world = dist.get_world_size()
+    mine = torch.tensor([elapsed, alone_elapsed if alone_elapsed is not None else float("nan"), local_cols],
+                        dtype=torch.float64, device=rdev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    rows = [p.cpu().tolist() for p in parts]
+    group = [r[0] for r in rows]
+    alone = [r[1] for r in rows]
+    cols = [r[2] for r in rows]
+    t_group = max(group)
+    total_cols = float(sum(cols))
+    fields = {"rank_ms_per_step": {"min": min(group) / steps * 1e3, "max": t_group / steps * 1e3,
+                                   "per_rank": [g / steps * 1e3 for g in group]}}
+    if alone_elapsed is not None:
+        alone_rates = [c * batch * steps / a for c, a in zip(cols, alone)]
+        slowest = max(range(world), key=lambda r: alone[r] / max(cols[r], 1.0))
+        fields["single_gpu_same_workload"] = {
+            "value": alone_rates[slowest], "unit": "columns/s", "ms_per_step": max(alone) / steps * 1e3,
+            "columns": cols[slowest], "per_rank_ms_per_step": [a / steps * 1e3 for a in alone],
+            "what": "every rank's own shard without the collective (same entry point: device output on torch's stream, "
+                    "read back), all ranks at once, one GPU each; value = the slowest rank's rate"}
+        fields["scaling_efficiency"] = (total_cols * batch * steps / t_group) / sum(alone_rates)
+    return t_group, total_cols, fields
 
 
 def proposals(d, key, n_states, batch, T_check=None):
@@ -411,6 +482,28 @@ def extra_configs(lib, d, data, fence):
                     "columns_per_token": (sum(len(f) for f in fw) / max(sum(f.compressed_length(plan["token_alphabet"])[0] for f in fw), 1))
                                          if plan["vector_tokens"] else 1.0})
 
+    # config[0] as worded: the reference's own model size (--states defaults to 10, scripts/isolation-model.py:43) on its
+    # only shipped alignment (examples/example_data.fa, pair hg18 / pantro2, 65,255 columns) - a latency, not a throughput
+    pi10, T10, E10 = d["iso10_t0_pi"], d["iso10_t0_T"], d["iso10_t0_E"]
+    pair = np.load(os.path.join(REPO, "tests", "golden", "example_pairs.npz"))["hg18__pantro2"]
+    _capi.check(lib.imc_dictionary_reset())
+    fw = [Forwarder.from_array(pair, 3)]
+    h = _capi.handle_array([f.handle for f in fw])
+    run("isolation-model 10 states, examples/example_data.fa hg18/pantro2, %d columns (BASELINE config[0], on the GPU)" % pair.size,
+        fw, lambda: _capi.forward1(h, 1, pi10, T10, E10), float(pair.size), 1, 200, 20)
+    res[-1]["us_per_evaluation"] = res[-1]["ms_per_step"] * 1e3
+    del fw, h
+    # the authors' own data scale: 100 files of 1 Mbp (simulations/isolation-model/simulate.sh:11), 10 states, one theta
+    t0 = time.time()
+    _capi.check(lib.imc_dictionary_reset())
+    fw = [Forwarder.from_array(data.pop("a10_%d" % i), 3) for i in range(100)]
+    recompress(fw)
+    h = _capi.handle_array([f.handle for f in fw])
+    run("isolation-model 10 states, 100 x 1000000-column synthetic chunks, one parameter set (the reference authors' data scale)",
+        fw, lambda: _capi.forward1(h, 100, pi10, T10, E10), 1e8, 1, 20, 5)
+    res[-1]["setup_s"] = time.time() - t0
+    res[-1]["us_per_evaluation"] = res[-1]["ms_per_step"] * 1e3
+    del fw, h
     # config[2]: ~150 states (IsolationMigrationModel(75, 75)), one 1e8-column alignment
     pi, T, E = d["im150_t0_pi"], d["im150_t0_T"], d["im150_t0_E"]
     t0 = time.time()
@@ -470,8 +563,12 @@ def rehearse_cpu(args, rank, world):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
-    chunks_per_rank = args.chunks or 4
-    mine = shard_indices(chunks_per_rank * world, rank, world)
+    if args.strong:
+        total_chunks = args.chunks or 8
+        mine = shard_indices(total_chunks, rank, world)
+    else:
+        total_chunks = (args.chunks or 4) * world
+        mine = shard_indices(total_chunks, rank, world)
 
     class FixedModel(object):
         def valid_parameters(self, p):
@@ -484,15 +581,34 @@ def rehearse_cpu(args, rank, world):
         return torch.tensor([-float(sum(1000 + i for i in mine))] * pis.shape[0], dtype=torch.float64)
 
     ll = DistributedLikelihood(FixedModel(), [], local_eval=local_eval)
-    value = ll(np.array([1.0]))
-    want = -float(sum(1000 + i for i in range(chunks_per_rank * world)))
+    pi, T, E = FixedModel().build_hidden_markov_model(None)
+    steps = max(args.steps, 1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        alone_value = ll.forward_params(pi, T, E, reduce=False)
+    alone_elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        value = ll(np.array([1.0]))
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    want = -float(sum(1000 + i for i in range(total_chunks)))
     ranks = dist.get_world_size() if world > 1 else 1
+    fields = {}
+    if world > 1:
+        elapsed, _, fields = scaling_report(torch, dist, torch.device("cpu"), elapsed, alone_elapsed, float(len(mine)), 1, steps)
     if rank == 0:
-        print(json.dumps({"metric": "launcher rehearsal (no GPU, INVALID as a measurement)", "value": 0.0, "unit": "columns/s",
-                          "n_gpus": args.gpus, "ranks": ranks, "backend": "gloo" if world > 1 else None,
-                          "steps": args.steps, "warmup": args.warmup, "valid": False,
-                          "config": {"workload": "rehearsal", "chunks": chunks_per_rank * world, "loglik": value,
-                                     "loglik_expected": want}}), flush=True)
+        rec = {"metric": "launcher rehearsal (no GPU, INVALID as a measurement)", "value": 0.0, "unit": "columns/s",
+               "n_gpus": args.gpus, "ranks": ranks, "backend": "gloo" if world > 1 else None,
+               "steps": args.steps, "warmup": args.warmup, "valid": False,
+               "scaling": "strong" if args.strong else "weak",
+               "config": {"workload": "rehearsal", "chunks": total_chunks, "chunks_this_rank": len(mine), "loglik": value,
+                          "loglik_expected": want, "alone_partial": alone_value}}
+        rec.update(fields)
+        print(json.dumps(rec), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

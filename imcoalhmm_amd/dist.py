@@ -48,7 +48,7 @@ class DistributedLikelihood(object):
     """
 
     def __init__(self, model, local_forwarders, group=None, device=None, local_eval=None, reduce_on_host=False,
-                 reduction="allreduce", recompress=True):
+                 reduction="allreduce", recompress=True, force_collective=False):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -71,7 +71,11 @@ class DistributedLikelihood(object):
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         # a single rank has nothing to reduce: the library's synchronous entry point writes the results straight into
         # host memory (no device tensor, no reduction kernel, no device-to-host copy through torch)
-        self._direct = local_eval is None and self.world_size == 1 and not reduce_on_host
+        # (force_collective=True keeps the device-output entry point and the collective even for one rank: how a
+        # single GPU exercises exactly the code N ranks run - RCCL initialisation, imc_forward_batch_device on torch's
+        # stream, the in-place all_reduce / the all_gather - tests/test_gpu_nccl.py)
+        self.force_collective = bool(force_collective)
+        self._direct = local_eval is None and self.world_size == 1 and not reduce_on_host and not self.force_collective
         self._harr = None
         if recompress and local_eval is None:   # this rank's shard: one pair dictionary trained on all of its chunks
             hmm.recompress(self.forwarders)
@@ -89,32 +93,35 @@ class DistributedLikelihood(object):
             ctypes.c_void_p(partial.data_ptr()), ctypes.c_void_p(stream)))
         return partial
 
-    def forward_params_batch(self, pis, Ts, Es):
-        """Global log-likelihoods (float64[B]) for B parameter sets; collective over the group."""
+    def forward_params_batch(self, pis, Ts, Es, reduce=True):
+        """Global log-likelihoods (float64[B]) for B parameter sets; collective over the group.
+        ``reduce=False``: this rank's partial sums only, through the same device-output entry point but without the
+        collective (bench.py times a rank's shard alone this way)."""
         pis, Ts, Es = hmm._batch_params(pis, Ts, Es)
         if self._direct:
             return hmm.forward_chunks_batch([f.handle for f in self.forwarders], pis, Ts, Es)
         partial = self._local_eval(pis, Ts, Es)
         if self.reduce_on_host:
             partial = partial.cpu()
-        if self.world_size > 1 and self.reduction == "ordered":
+        collective = reduce and self._dist.is_initialized() and (self.world_size > 1 or self.force_collective)
+        if collective and self.reduction == "ordered":
             parts = [self._torch.empty_like(partial) for _ in range(self.world_size)]
             self._dist.all_gather(parts, partial, group=self.group)
             total = np.zeros(partial.shape[0], dtype=np.float64)
             for part in parts:                          # rank order, left to right from 0.0
                 total = total + part.detach().cpu().numpy()
             return total
-        if self.world_size > 1:
+        if collective:
             self._dist.all_reduce(partial, op=self._dist.ReduceOp.SUM, group=self.group)
         return partial.detach().cpu().numpy()
 
-    def forward_params(self, pi, T, E):
+    def forward_params(self, pi, T, E, reduce=True):
         pi, T, E = hmm._params(pi, T, E)
         if self._direct:
             if self._harr is None:
                 self._harr = _capi.handle_array([f.handle for f in self.forwarders])
             return _capi.forward1(self._harr, len(self.forwarders), pi, T, E)
-        return float(self.forward_params_batch(pi[None], T[None], E[None])[0])
+        return float(self.forward_params_batch(pi[None], T[None], E[None], reduce=reduce)[0])
 
     def __call__(self, *parameters):
         if not self.model.valid_parameters(*parameters):
@@ -144,7 +151,7 @@ class SplitAlignmentLikelihood(object):
     ``local_state(pis, Ts, Es, as_operator) -> (values, exponents)`` may be injected (CPU/gloo tests).
     """
 
-    def __init__(self, model, local_forwarder, group=None, local_state=None, gather_device=None):
+    def __init__(self, model, local_forwarder, group=None, local_state=None, gather_device=None, force_collective=False):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -155,6 +162,7 @@ class SplitAlignmentLikelihood(object):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self._local_state = local_state or self._hip_state
+        self.force_collective = bool(force_collective)   # one rank still goes through all_gather (tests/test_gpu_nccl.py)
 
     def _hip_state(self, pis, Ts, Es, as_operator):
         values, exps = hmm.forward_states([self.forwarder.handle], pis, Ts, Es, as_operator)
@@ -176,7 +184,7 @@ class SplitAlignmentLikelihood(object):
         mine = torch.from_numpy(rec)
         if self.gather_device is not None:
             mine = mine.to(self.gather_device)
-        if self.world_size > 1:
+        if self.world_size > 1 or (self.force_collective and self._dist.is_initialized()):
             parts = [torch.empty_like(mine) for _ in range(self.world_size)]
             self._dist.all_gather(parts, mine, group=self.group)
         else:
@@ -206,7 +214,7 @@ class ProposalShardedLikelihood(object):
     (CPU/gloo tests); by default it is ``forward_chunks_batch`` over this process's forwarders.
     """
 
-    def __init__(self, model, forwarders, group=None, local_eval=None, gather_device=None):
+    def __init__(self, model, forwarders, group=None, local_eval=None, gather_device=None, force_collective=False):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -218,6 +226,7 @@ class ProposalShardedLikelihood(object):
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self._local_eval = local_eval or (lambda pis, Ts, Es: hmm.forward_chunks_batch(
             [f.handle for f in self.forwarders], pis, Ts, Es))
+        self.force_collective = bool(force_collective)   # one rank still goes through all_gather (tests/test_gpu_nccl.py)
 
     def forward_params_batch(self, pis, Ts, Es):
         torch = self._torch
@@ -231,7 +240,7 @@ class ProposalShardedLikelihood(object):
         t = torch.from_numpy(vals)
         if self.gather_device is not None:
             t = t.to(self.gather_device)
-        if self.world_size > 1:
+        if self.world_size > 1 or (self.force_collective and self._dist.is_initialized()):
             parts = [torch.empty_like(t) for _ in range(self.world_size)]
             self._dist.all_gather(parts, t, group=self.group)
         else:

@@ -42,3 +42,23 @@ def test_single_rank_reports_one_rank():
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert rec["n_gpus"] == 1 and rec["ranks"] == 1 and rec["backend"] is None
+
+
+def test_multi_rank_line_carries_its_own_single_gpu_base():
+    """An N > 1 line must be judgeable by itself: the ranks' shards timed alone (no collective), the efficiency against
+    that base, and every rank's step time; --strong deals a FIXED number of chunks over the ranks."""
+    for extra, total, scaling in (([], 8, "weak"), (["--strong", "--chunks", "6"], 6, "strong")):
+        out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse-cpu", "--steps", "3", "--warmup", "0"] + extra,
+                             capture_output=True, text=True, timeout=300, env=_clean_env())
+        assert out.returncode == 0, out.stderr[-2000:]
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert rec["scaling"] == scaling and rec["config"]["chunks"] == total
+        assert rec["config"]["chunks_this_rank"] == total // 2
+        assert rec["config"]["loglik"] == rec["config"]["loglik_expected"]
+        base = rec["single_gpu_same_workload"]
+        assert base["value"] > 0 and base["ms_per_step"] > 0 and len(base["per_rank_ms_per_step"]) == 2
+        assert 0 < rec["scaling_efficiency"] < 10
+        per = rec["rank_ms_per_step"]
+        assert len(per["per_rank"]) == 2 and per["min"] <= per["max"] and per["max"] == max(per["per_rank"])
+        # rank 0's partial alone is only its own shard: chunks 0, 2, 4, ...
+        assert rec["config"]["alone_partial"] == -float(sum(1000 + i for i in range(0, total, 2)))

@@ -80,6 +80,26 @@ SCRIPT = textwrap.dedent('''
     check(70, [1, 16, 300, 60000, 36000], (0, 1, 2, 3), B=1)
     check(150, [90, 130_000], (1, 3), B=1)
     check(150, [40_000, 9_000], (5,), seg=4096, B=1)                   # GEMM chain + rank-one hand-off rounds
+    # The blocked MFMA kernels on a stream with NO merged tokens (mode 5: raw symbols, three table entries and the
+    # identity; the launch carries no merge lists: tab_order / tab_lvl are null, tab_nlvl == 0).  Round 2's
+    # gpurun_out/r2/pytest_i.log is this shape: an uncommitted build whose table prologue copied tab_lvl[0 .. tab_nlvl]
+    # without looking at tab_nlvl read through the null pointer and the runtime aborted the process (DESIGN 8a(f)).
+    for n in (10, 20):
+        pi_, T_, E_ = synth.random_hmm(n, 3, seed=4400 + n, stay=0.97)
+        obs_ = synth.sample_alignment(pi_, T_, E_, 65_255, seed=n)
+        L.imc_set_compression(5); L.imc_dictionary_reset()
+        f_ = Forwarder.from_array(obs_, 3)
+        assert f_.compressed_length()[1] == 3                          # no dictionary: zero merged tokens
+        for variant in (3, 5, 4):
+            L.imc_set_blocked_kernel(variant)
+            for seg in (0, 48, 1000):
+                L.imc_set_segment_length(seg)
+                got_ = f_.forward(pi_, T_, E_)
+                assert "k_zpropagate3" in _capi.last_plan()["kernels"] and "[columns]" in _capi.last_plan()["kernels"], _capi.last_plan()["kernels"]
+                assert rel(got_, oracle_lib.forward_scaled(pi_, T_, E_, obs_)) < 1e-11, (n, variant, seg)
+        L.imc_set_segment_length(0); L.imc_set_blocked_kernel(4); L.imc_set_compression(1)
+        del f_
+    print("raw-blocked ok", flush=True)
     print("families ok", flush=True)
 ''') % (REPO, REPO)
 
@@ -92,4 +112,4 @@ def test_create_free_flip_create_under_guard_pages(tmp_path):
     tail = (out.stdout[-1500:], out.stderr[-3000:])
     if "hipMemAddressReserve" in out.stderr or "hipMemCreate" in out.stderr or "hipMemGetAllocationGranularity" in out.stderr:
         pytest.skip("HIP virtual-memory management is unavailable on this box: %r" % (tail,))
-    assert out.returncode == 0 and "sequence ok" in out.stdout and "families ok" in out.stdout, tail
+    assert out.returncode == 0 and "sequence ok" in out.stdout and "families ok" in out.stdout and "raw-blocked ok" in out.stdout, tail
