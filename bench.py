@@ -139,7 +139,10 @@ def read_profile(lib):
 
 
 def timed_steps(lib, step, steps, warmup, fence):
-    """W untimed + K timed calls of step(), bracketed by fence(); HIP-event kernel timing over the timed region."""
+    """W untimed + K timed calls of step(), bracketed by fence(); HIP-event kernel timing over the timed region.
+    (Checked in round 3: the events cost the timed region nothing measurable - 0.2852 ms per step without them, 0.2835
+    with, same process - although a rocprofv3 timeline shows ~5 us queue gaps around an event-bracketed kernel: those
+    exist under the tracer only.)"""
     value = None
     for _ in range(warmup):
         value = step()

@@ -138,6 +138,9 @@ struct Ctx {
     int z4_stream = -1;       // k_zpropagate4's table: -1 = streamed (nothing cached in LDS) while the launch's tables are
                               // cache resident, 0 = always the hybrid LDS cache, 1 = always streamed (IMC_Z4_STREAM)
     bool table_pairs = true;  // IMC_TABLE_PAIRS=0: k_zpropagate4's table one dictionary depth per launch (A/B measurements)
+    bool table_triples = false; // IMC_TABLE_TRIPLES=1: three depths per launch, one wavefront per token (k_z4_level3) - measured no
+                               // faster than pairs (54 vs 52.5 us at 4096 tokens: 2197 wavefronts in the depth 7-9 launch), kept for A/B
+    bool fuse_head = true;    // IMC_FUSE_HEAD=0: k_stage_params + k_z4_raw as launches of their own (A/B measurements)
     bool pack_table = true;   // IMC_PACK_TABLE=0: the mat-vec chain reads the padded table (A/B measurements)
     bool guard = false;       // IMC_GUARD=1: every device buffer ends flush against an unmapped guard range (dev_alloc)
     bool use_graphs = false;  // IMC_GRAPH=1: replay each plan's launch sequence as a hipGraph (measured: no gain, the
@@ -185,6 +188,8 @@ int ensure_ctx()
     if (const char *r1 = std::getenv("IMC_RANK1")) g.rank1_handoff = std::atoi(r1) != 0;
     if (const char *pt = std::getenv("IMC_PACK_TABLE")) g.pack_table = std::atoi(pt) != 0;
     if (const char *tp = std::getenv("IMC_TABLE_PAIRS")) g.table_pairs = std::atoi(tp) != 0;
+    if (const char *fh = std::getenv("IMC_FUSE_HEAD")) g.fuse_head = std::atoi(fh) != 0;
+    if (const char *tt = std::getenv("IMC_TABLE_TRIPLES")) g.table_triples = std::atoi(tt) != 0;
     if (const char *zs = std::getenv("IMC_Z4_STREAM")) { const int v = std::atoi(zs); if (v >= -1 && v <= 1) g.z4_stream = v; }
     g.pid = me;
     g.ready = true;
@@ -487,12 +492,16 @@ struct KernelChoice {
     void (*zip4s)(BigArgs) = nullptr, (*zip4sw)(BigArgs) = nullptr;   // ... with the STREAMED table (nothing cached in LDS)
     void (*zip4_raw)(BigArgs) = nullptr;
     void (*zip4_level)(BigArgs, int, int) = nullptr;
-    void (*zip4_level2)(BigArgs, const int4 *, int, int) = nullptr;   // two dictionary depths per launch
+    void (*zip4_level2)(BigArgs, const int4 *, int, int, const double *) = nullptr;   // two dictionary depths per launch
+    void (*zip4_level2_first)(BigArgs, const int4 *, int, int, const double *) = nullptr;   // ... the first one: parameters + raw operators too
+    void (*zip4_level3)(BigArgs, const int4 *, int, int, const double *) = nullptr;        // three dictionary depths per launch
+    void (*zip4_level3_first)(BigArgs, const int4 *, int, int, const double *) = nullptr;
+    size_t (*zip4_level3_lds)(size_t) = nullptr;
     size_t (*zip4_lds)(int, int) = nullptr;
     int (*zip4_max_hot)(int, size_t) = nullptr;
     int tok_doubles = 0;               // doubles per table entry of the MFMA kernels
     bool chain_self_emax = false;      // the stitch kernel finds the units' largest exponents itself (no k_emax launch)
-    bool zip4_attr_set = false, zip4w_attr_set = false, zip4s_attr_set = false, zip4sw_attr_set = false;
+    bool zip4_attr_set = false, zip4w_attr_set = false, zip4s_attr_set = false, zip4sw_attr_set = false, zip4_attr_l3 = false;
     // the blocked kernel in use (g.blocked_variant) and its LDS need for an alphabet of A tokens
     bool use3() const;
     size_t blocked_lds(int A) const { return use3() ? zip3_lds(A) : zip2_lds(A); }
@@ -518,7 +527,11 @@ KernelChoice make_kc()
             k.zip4sw = k_zpropagate4<NP / 4, true, false>;
             k.zip4_raw = k_z4_raw<NP / 4>;
             k.zip4_level = k_z4_level<NP / 4>;
-            k.zip4_level2 = k_z4_level2<NP / 4>;
+            k.zip4_level2 = k_z4_level2<NP / 4, false>;
+            k.zip4_level2_first = k_z4_level2<NP / 4, true>;
+            k.zip4_level3 = k_z4_level3<NP / 4, false>;
+            k.zip4_level3_first = k_z4_level3<NP / 4, true>;
+            k.zip4_level3_lds = &Z4L3Geom<NP / 4>::lds_bytes;
             k.zip4_lds = &Zip4Geom<NP / 4>::lds_bytes;
             k.zip4_max_hot = &Zip4Geom<NP / 4>::max_hot;
         }
@@ -566,8 +579,8 @@ KernelChoice *choose_kernel(int N, bool prefer_gemm)
 
 void reset_kernel_attributes()
 {
-    for (auto &k : kChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.zip4w_attr_set = k.zip4s_attr_set = k.zip4sw_attr_set = k.plain_attr_set = false;
-    for (auto &k : kMidChoices) k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.zip4w_attr_set = k.zip4s_attr_set = k.zip4sw_attr_set = k.plain_attr_set = false;
+    for (auto &k : kChoices) k.zip4_attr_l3 = k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.zip4w_attr_set = k.zip4s_attr_set = k.zip4sw_attr_set = k.plain_attr_set = false;
+    for (auto &k : kMidChoices) k.zip4_attr_l3 = k.zip_attr_set = k.zip2_attr_set = k.zip3_attr_set = k.zip4_attr_set = k.zip4w_attr_set = k.zip4s_attr_set = k.zip4sw_attr_set = k.plain_attr_set = false;
 }
 
 // ---- launch plan ----------------------------------------------------------------------------------
@@ -593,6 +606,8 @@ struct Group {             // one propagate launch
     int4 *d_tab_desc = nullptr;               // hybrid table: {token, left, right, 0} per entry of the depth order
     int4 *d_tab_desc2 = nullptr;              // ... two int4 per entry of the two-depths-per-launch schedule (k_z4_level2)
     std::vector<std::pair<int, int>> tab2;    // ... (first entry, entries) per launch
+    int4 *d_tab_desc3 = nullptr;              // ... three int4 per token of the three-depths-per-launch schedule (k_z4_level3): {token, leaves 0-2}, {leaves 3-6}, {leaf 7}
+    std::vector<std::pair<int, int>> tab3;
     std::vector<int> tab_lvl;                 // host copy of the depth offsets
     int tab_nlvl = 0;
     double *d_Ctab = nullptr;
@@ -672,7 +687,7 @@ struct Plan {
         if (graph) (void)hipGraphExecDestroy(graph);
         dev_free(d_segs); dev_free(d_vecs); dev_free(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_desc2); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_Cpack); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
+        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_desc2); dev_free(gr.d_tab_desc3); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_Cpack); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
         dev_free(d_params); dev_free(d_out);
         for (int k = 0; k < 2; ++k) { (void)hipHostFree(h_params[k]); if (ev_params[k]) (void)hipEventDestroy(ev_params[k]); }
         (void)hipHostFree(h_out);
@@ -1287,6 +1302,35 @@ struct PlanBuilder {
                         gr.tab2.push_back({first, (int)(d2.size() / 2) - first});
                     }
                     if (e == hipSuccess && !d2.empty()) e = up((void **)&gr.d_tab_desc2, d2.data(), d2.size() * sizeof(int4));
+                    // three depths per launch (k_z4_level3): launch k builds depths 3k+1 .. 3k+3, one wavefront per token;
+                    // a token's eight leaves are the nodes of its dictionary tree that lie at depth <= 3k (already in the
+                    // table), a ready node in the first leaf of its range and the identity in the rest of it
+                    std::vector<int4> d3;
+                    gr.tab3.clear();
+                    for (int d = 0; d < gr.tab_nlvl; d += 3) {
+                        const int first = (int)(d3.size() / 3);
+                        const int d_ready = dd.depth[order[lvl[d]]] - 1;            // entries up to this depth exist
+                        for (int k = lvl[d]; k < lvl[std::min(d + 3, gr.tab_nlvl)]; ++k) {
+                            int leaves[8];
+                            for (int &x : leaves) x = gr.A;                       // the identity entry
+                            struct Fill {
+                                const DictDev &dd; int S, d_ready; int *leaves;
+                                void operator()(int t, int lo, int hi) const
+                                {
+                                    if (t < S || dd.depth[t] <= d_ready || hi - lo == 1) { leaves[lo] = t; return; }
+                                    const int mid = (lo + hi) / 2;
+                                    (*this)((int)dd.dict.left[t], lo, mid);
+                                    (*this)((int)dd.dict.right[t], mid, hi);
+                                }
+                            } fill{dd, S, d_ready, leaves};
+                            fill((int)order[k], 0, 8);
+                            d3.push_back(make_int4((int)order[k], leaves[0], leaves[1], leaves[2]));
+                            d3.push_back(make_int4(leaves[3], leaves[4], leaves[5], leaves[6]));
+                            d3.push_back(make_int4(leaves[7], 0, 0, 0));
+                        }
+                        gr.tab3.push_back({first, (int)(d3.size() / 3) - first});
+                    }
+                    if (e == hipSuccess && !d3.empty()) e = up((void **)&gr.d_tab_desc3, d3.data(), d3.size() * sizeof(int4));
                 }
             }
             if (!gr.big || e != hipSuccess) continue;
@@ -1467,7 +1511,26 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
     // from the mapped staging slot: a copy command costs its own ~3 us plus a ~10 us hand-over between the copy and the
     // first kernel (rocprofv3 kernel trace), a kernel in the same queue costs one launch.
     const size_t pbytes = (size_t)B * p->pstride * 8;
-    if (pbytes <= STAGE_KERNEL_MAX_BYTES) {
+    // One streamed / hybrid-table group and nothing else (BASELINE config[1], the config[3] slice): the first table launch
+    // fetches the parameters itself (k_z4_level2<., true>) - no k_stage_params, no k_z4_raw.
+    bool fuse_head = false, direct_params = false;
+    {
+        int active = 0;
+        const Group *only = nullptr;
+        for (const Group &gr : p->groups)
+            if (gr.n_vecs) { ++active; only = &gr; }
+        const size_t head_lds = p->pstride * 8;
+        fuse_head = g.fuse_head && active == 1 && only->zip4 && g.table_pairs && only->d_tab_desc2 && !only->tab2.empty() &&
+                    kc->zip4_level2_first && pbytes <= STAGE_KERNEL_MAX_BYTES && head_lds <= 16 * 1024;
+        // ... and a SMALL launch of the LDS-table MFMA kernel (the reference's own data sizes: one alignment of 1e5..1e6
+        // columns): each of its few workgroups fetches the parameter set itself
+        direct_params = g.fuse_head && active == 1 && only->zip2 && !only->zip4 && kc->use3() && pbytes <= STAGE_KERNEL_MAX_BYTES &&
+                        only->blocks.size() * (size_t)B <= 32 && p->pstride * 8 <= 8192 &&
+                        ((kc->blocked_lds(only->A) + 15) & ~(size_t)15) + p->pstride * 8 <= LDS_BUDGET;
+    }
+    if (fuse_head || direct_params) {
+        // (nothing to enqueue here)
+    } else if (pbytes <= STAGE_KERNEL_MAX_BYTES) {
         const unsigned n2 = (unsigned)(pbytes / 16);
         hipLaunchKernelGGL(k_stage_params, dim3((n2 + 255) / 256), dim3(256), 0, stream,
                            reinterpret_cast<const double2 *>(p->h_params_dev[p->slot]), reinterpret_cast<double2 *>(p->d_params), n2);
@@ -1501,7 +1564,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             BigArgs ba;
             ba.segs = p->d_segs; ba.seg_ids = gr.d_seg_ids; ba.seg_vec0 = gr.d_seg_out; ba.blocks = nullptr;
             ba.n_group_segs = (uint32_t)gr.seg_ids.size(); ba.n_vecs_total = p->n_vecs;
-            ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
+            ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.params_src = nullptr; ba.pstride = p->pstride; ba.PP = NP;
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
             ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex;
             ba.Cpack = gr.d_Cpack; ba.TS = N + (N & 1);
@@ -1585,7 +1648,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             BigArgs ba;
             ba.segs = p->d_segs; ba.seg_ids = nullptr; ba.seg_vec0 = nullptr; ba.blocks = gr.d_blocks;
             ba.n_group_segs = (uint32_t)gr.blocks.size(); ba.n_vecs_total = p->n_vecs;
-            ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.pstride = p->pstride; ba.PP = NP;
+            ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.params_src = nullptr; ba.pstride = p->pstride; ba.PP = NP;
             ba.tok_left = gr.zip ? gr.dict->d_left : nullptr; ba.tok_right = gr.zip ? gr.dict->d_right : nullptr;
             ba.Ctab = nullptr; ba.cex = nullptr; ba.Cpack = nullptr; ba.TS = 0;
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
@@ -1595,12 +1658,39 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                 // hybrid table: one workgroup per parameter set builds the operators in global memory (they stay in
                 // L2), then the scan caches the hot ones in LDS and streams the rest a step ahead
                 ba.Ctab = gr.d_Ctab; ba.cex = gr.d_cex;
-                hipLaunchKernelGGL(kc->zip4_raw, dim3((unsigned)S + 1, (unsigned)B), dim3(256), 0, stream, ba);
-                HIP_TRY(hipGetLastError());
-                if (g.table_pairs && gr.d_tab_desc2) {
+                if (!fuse_head) {
+                    hipLaunchKernelGGL(kc->zip4_raw, dim3((unsigned)S + 1, (unsigned)B), dim3(256), 0, stream, ba);
+                    HIP_TRY(hipGetLastError());
+                }
+                if (g.table_pairs && g.table_triples && gr.d_tab_desc3) {
+                    bool head = fuse_head;
+                    if (!kc->zip4_attr_l3) {
+                        HIP_TRY(hipFuncSetAttribute((const void *)kc->zip4_level3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+                        HIP_TRY(hipFuncSetAttribute((const void *)kc->zip4_level3_first, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+                        kc->zip4_attr_l3 = true;
+                    }
+                    for (const auto &lc : gr.tab3) {          // three dictionary depths per launch, one wavefront per token
+                        const dim3 grid((unsigned)(lc.second + Z4L3_WAVES - 1) / Z4L3_WAVES, (unsigned)B);
+                        if (head)
+                            hipLaunchKernelGGL(kc->zip4_level3_first, grid, dim3(Z4L3_WAVES * 64), kc->zip4_level3_lds(p->pstride), stream, ba,
+                                               (const int4 *)gr.d_tab_desc3, lc.first, lc.second, (const double *)p->h_params_dev[p->slot]);
+                        else
+                            hipLaunchKernelGGL(kc->zip4_level3, grid, dim3(Z4L3_WAVES * 64), kc->zip4_level3_lds(0), stream, ba,
+                                               (const int4 *)gr.d_tab_desc3, lc.first, lc.second, (const double *)nullptr);
+                        head = false;
+                        HIP_TRY(hipGetLastError());
+                    }
+                } else if (g.table_pairs && gr.d_tab_desc2) {
+                    bool head = fuse_head;
                     for (const auto &lc : gr.tab2) {          // two dictionary depths per launch
-                        hipLaunchKernelGGL(kc->zip4_level2, dim3((unsigned)(lc.second + 3) / 4, (unsigned)B), dim3(64), 0, stream, ba,
-                                           (const int4 *)gr.d_tab_desc2, lc.first, lc.second);
+                        if (head)
+                            hipLaunchKernelGGL(kc->zip4_level2_first, dim3((unsigned)(lc.second + 3) / 4, (unsigned)B), dim3(64),
+                                               p->pstride * 8, stream, ba,
+                                               (const int4 *)gr.d_tab_desc2, lc.first, lc.second, (const double *)p->h_params_dev[p->slot]);
+                        else
+                            hipLaunchKernelGGL(kc->zip4_level2, dim3((unsigned)(lc.second + 3) / 4, (unsigned)B), dim3(64), 0, stream, ba,
+                                               (const int4 *)gr.d_tab_desc2, lc.first, lc.second, (const double *)nullptr);
+                        head = false;
                         HIP_TRY(hipGetLastError());
                     }
                 } else
@@ -1631,8 +1721,9 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                                             (int)LDS_BUDGET));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(v3 ? kc->zip3 : kc->zip2, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64),
-                               kc->blocked_lds(gr.A), stream, ba);
+            size_t lds3 = kc->blocked_lds(gr.A);
+            if (direct_params) { ba.params_src = p->h_params_dev[p->slot]; lds3 = ((lds3 + 15) & ~(size_t)15) + p->pstride * 8; }
+            hipLaunchKernelGGL(v3 ? kc->zip3 : kc->zip2, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64), lds3, stream, ba);
             note(std::string(v3 ? "k_zpropagate3<" : "k_zpropagate2<") + std::to_string(NP / 4) + ">" + strm);
             if (gr.zip) { lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A); }
             else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }

@@ -34,6 +34,8 @@ struct BigArgs {
     uint32_t n_vecs_total;
     int N, S, A;
     const double *params;         // per parameter set: pi[PP] | Tp[PP*PP] | Et[S*PP]   (PP = params' padding)
+    const double *params_src;     // k_zpropagate3, small launches: non-null = fetch the parameters from here (the mapped staging slot on the
+                                  // host) into LDS instead of reading a.params - the evaluation then has no k_stage_params launch
     size_t pstride;
     int PP;
     const uint16_t *tok_left, *tok_right;

@@ -151,6 +151,19 @@ __device__ __forceinline__ int wave_max_i32(int v)
     for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
     return __builtin_amdgcn_readfirstlane(v);
 }
+// The same maximum by DPP moves (row shifts inside the 16-lane rows, then the two row broadcasts of gfx9): seven VALU
+// instructions instead of six ds_bpermute round trips (~80 instead of ~500 cycles of dependent latency) - for use on a
+// serial chain (k_chain's per-step exponent maximum).
+__device__ __forceinline__ int wave_max_i32_dpp(int v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));   // row_shr:8  -> lane 15 of a row: the row's maximum
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ int wave_min_i32(int v)
 {
 #pragma unroll

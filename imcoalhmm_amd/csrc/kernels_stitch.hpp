@@ -103,14 +103,13 @@ __global__ __launch_bounds__(((NP + 63) / 64) * 64) void k_chain(
         }
     } else {
     double2 pk[D > 0 ? D : 1][NP / 2];
-    int exr[D > 0 ? D : 1], emr[D > 0 ? D : 1];
+    int exr[D > 0 ? D : 1];
     auto fetch = [&](int t, int slot) {   // slot is a compile-time constant at every call site
         const size_t v0 = (size_t)vbase + (size_t)t * N;
-        // the unit's largest column exponent, found here - D steps ahead of its use, off the serial chain - instead
-        // of by a k_emax launch per level (lanes beyond N repeat column 0, which is part of the maximum anyway)
-        const int exv = EXb[v0 + ii];
-        emr[slot] = wave_max_i32(exv);
-        exr[slot] = exv;
+        // Loads only, D steps ahead of their use.  (Round 2 reduced the exponents to their maximum right here: that
+        // waited for the load it had just issued and then ran six ds_bpermute round trips - ~0.5 us in front of every
+        // step of the serial chain, most of the 0.65 us a step took.)  Lanes beyond N repeat column 0.
+        exr[slot] = EXb[v0 + ii];
         const double2 *row = reinterpret_cast<const double2 *>(Pb + (v0 + ii) * NP);
 #pragma unroll
         for (int m = 0; m < NP / 2; ++m) pk[slot][m] = row[m];
@@ -124,7 +123,8 @@ __global__ __launch_bounds__(((NP + 63) / 64) * 64) void k_chain(
         for (int s = 0; s < D; ++s) {
             const int t = t0 + s;
             if (t < nsteps) {   // wave-uniform
-                const int em = emr[s];
+                // the unit's largest column exponent, found here instead of by a k_emax launch per level: seven DPP moves
+                const int em = wave_max_i32_dpp(exr[s]);
                 if (mine) w[buf][i] = ldexp(a, exr[s] - em);
                 else if (i < NP) w[buf][i] = 0.0;
                 double2 cur[NP / 2];

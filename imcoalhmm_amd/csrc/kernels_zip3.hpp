@@ -111,6 +111,92 @@ __device__ __forceinline__ void zip3_rescale(double (&P)[NT][NT], int &ex)
     ex += e;
 }
 
+// ---- fold the workgroup's n segments into one: P_0 <- P_{n-1} ... P_1 P_0 ------------------------------------------------
+// Slot s = 4 * wavefront + block holds segment s's operator P (registers, the layout of an MFMA B operand) and exponent.
+// X: exchange area of Z2SLOTS entries of TOK doubles (the operator table's space once it is dead), xe: Z2SLOTS ints.
+//   stage A - inside each wavefront, no workgroup barrier: block 1 -> 0 and 3 -> 2 (one step), then 2 -> 0 (one step);
+//             a partner hands its operator over through X in the table's layout (an A operand's rows) - LDS executes a
+//             wavefront's own instructions in order - and the receiving block multiplies it on: an ordinary step.
+//   stage B - the (up to) eight wavefront products meet in X behind ONE workgroup barrier and wavefront 0 alone folds
+//             them: pairs (2b, 2b + 1) in its four blocks, then 1 -> 0 and 3 -> 2, then 2 -> 0 - three steps with the
+//             MFMA pipe to itself.
+// A block without a partner (ragged n) still issues the step - the matrix instruction is wavefront-wide - on whatever X
+// holds and keeps its own P.  Round 2's fold was five workgroup-wide levels (two barriers and a step by all eight
+// wavefronts each): 16 us at N = 20 (in-kernel timestamps, profiles/r02_z4_phase_times.txt).
+// TABLE_LIVE: X overlays an LDS table that other wavefronts may still be reading -> one more barrier in front.
+template <int NT, bool TABLE_LIVE, bool RESCALE = true>
+__device__ __forceinline__ void zip3_fold(double (&P)[NT][NT], int &ex, double *X, int *xe, int n, int slot, int wv, int lo, int lx)
+{
+    using Geo = Zip3Geom<NT>;
+    constexpr int TOK = Geo::TOK;
+    if (n <= 1) return;                                     // workgroup-uniform
+    const int lane = threadIdx.x & 63;                      // (wv: this wavefront's index among those that fold together)
+    const int q = lane >> 4, bq = (lane >> 2) & 3, r = lane & 3;
+    double Q[NT][NT], al[NT];
+    auto put = [&](int area) __attribute__((always_inline)) {
+        double *dst = X + (size_t)area * TOK;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) dst[Geo::idx(4 * K + q, 4 * J + r)] = P[K][J];
+        if (q == 0 && r == 0) xe[area] = ex;
+    };
+    auto take = [&](int area, bool act) __attribute__((always_inline)) {     // P <- X[area] * P where act
+        const double *src = X + (size_t)area * TOK;
+        zip3_load_row<NT>(al, src, 0, lo, lx);
+        zip3_step<NT>(P, Q, src, src, al, lo, lx);
+        const int e = xe[area];
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) P[K][J] = act ? Q[K][J] : P[K][J];
+        ex += act ? e : 0;
+        if constexpr (RESCALE) zip3_rescale<NT>(P, ex);   // (a caller that folds at most a few normalised operators rescales once, at the end)
+    };
+    if constexpr (TABLE_LIVE) __syncthreads();
+    // ---- stage A ----
+    if (wv * 4 + 1 < n) {                                   // (wavefront-uniform: this wavefront holds at least two segments)
+        if ((bq & 1) && slot < n) put(slot);
+        wave_fence();
+        take(slot + 1 < Z2SLOTS ? slot + 1 : slot, !(bq & 1) && slot + 1 < n);
+        if (wv * 4 + 2 < n) {
+            wave_fence();                                   // (the reads of level 1 are done before area slot 2 is rewritten)
+            if (bq == 2 && slot < n) put(slot);
+            wave_fence();
+            take(slot + 2 < Z2SLOTS ? slot + 2 : slot, bq == 0 && slot + 2 < n);
+        }
+    }
+    if (n <= 4) return;
+    // ---- stage B ----
+    const int nw = (n + 3) / 4;                             // wavefronts that hold segments
+    if (bq == 0 && wv < nw && wv > 0) put(wv * 4);          // (wavefront 0's own product stays in its registers ...)
+    if (wv == 0) { wave_fence(); if (bq == 0) put(0); }     // (... but blocks 1..3 of wavefront 0 need it from X as well)
+    __syncthreads();
+    if (wv != 0) return;
+    {   // level 3: block b takes the pair (2b, 2b + 1)
+        const int lo_w = 2 * bq, hi_w = 2 * bq + 1;
+        const double *src = X + (size_t)(lo_w < nw ? lo_w : 0) * 4 * TOK;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) P[K][J] = src[Geo::idx(4 * K + q, 4 * J + r)];
+        ex = xe[(lo_w < nw ? lo_w : 0) * 4];
+        take((hi_w < nw ? hi_w : 0) * 4, hi_w < nw);
+    }
+    if (nw > 2) {                                           // level 4: 1 -> 0, 3 -> 2 (blocks hold wavefronts 2b, 2b + 1)
+        wave_fence();
+        if (bq & 1) put(bq);                                // areas 1 and 3: wavefront 0's own slots, free since stage A
+        wave_fence();
+        take(bq + 1 < 4 ? bq + 1 : bq, !(bq & 1) && 2 * (bq + 1) < nw);
+    }
+    if (nw > 4) {                                           // level 5: 2 -> 0
+        wave_fence();
+        if (bq == 2) put(2);
+        wave_fence();
+        take(bq + 2 < 4 ? bq + 2 : bq, bq == 0);
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigArgs a)
 {
@@ -124,6 +210,27 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const double *pp = a.params + (size_t)b * a.pstride;
+    if (a.params_src) {
+        // small launch: every workgroup fetches the parameter set straight from the caller's mapped staging slot (all of
+        // a lane's loads in flight together: host memory, ~2 us per round trip) into LDS behind the table's lists
+        double *lp = reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + ((Geo::lds_bytes(a.A) + 15) & ~(size_t)15));
+        const double *src = a.params_src + (size_t)b * a.pstride;
+        for (int k0 = 0; k0 < (int)a.pstride; k0 += 2 * 2 * THREADS) {
+            double2 v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = k0 + (u * THREADS + tid) * 2;
+                v[u] = k < (int)a.pstride ? *reinterpret_cast<const double2 *>(src + k) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = k0 + (u * THREADS + tid) * 2;
+                if (k < (int)a.pstride) *reinterpret_cast<double2 *>(lp + k) = v[u];
+            }
+        }
+        __syncthreads();
+        pp = lp;
+    }
     const double *pi_p = pp;
     const double *Tp = pp + a.PP;
     const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
@@ -269,40 +376,9 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
         masked_block(bi, min(RESCALE_EVERY, (maxlen - bi * RESCALE_EVERY + 1) & ~1));
     zip3_rescale<NT>(P, ex);
 
-    // ---- fold the workgroup's segments into one: P_0 <- P_{n-1} ... P_1 P_0 (binary tree through LDS) ----
-    // The operator table is dead once every wavefront is here; its space becomes the exchange area (slot s holds the
-    // operator of segment s in the table's own layout, entry Z2SLOTS the identity), and a fold step is an ordinary
-    // token step whose "token operator" is the partner slot's P.
-    for (int stride = 1; stride < Z2SLOTS; stride <<= 1) {
-        if ((int)blk.n <= stride) break;          // workgroup-uniform
-        __syncthreads();                          // table (or previous level's exchange data) no longer read
-        if (stride == 1) {
-            for (int idx = tid; idx < NP * NP; idx += THREADS) {
-                const int i = idx / NP, j = idx - i * NP;
-                C[(size_t)Z2SLOTS * TOK + Geo::idx(i, j)] = i == j ? 1.0 : 0.0;
-            }
-            if (tid == 0) cex[Z2SLOTS] = 0;
-        }
-        if (valid && (slot & stride) && !(slot & (stride - 1))) {   // this slot is a partner ("hi") at this level
-            double *dst = C + (size_t)slot * TOK;
-#pragma unroll
-            for (int K = 0; K < NT; ++K)
-#pragma unroll
-                for (int J = 0; J < NT; ++J) dst[Geo::idx(4 * K + q, 4 * J + r)] = P[K][J];
-            if (q == 0 && r == 0) cex[slot] = ex;
-        }
-        __syncthreads();
-        const bool act = valid && !(slot & (2 * stride - 1)) && slot + stride < (int)blk.n;
-        const int src = act ? slot + stride : Z2SLOTS;
-        zip3_load_row<NT>(arow, C + (size_t)src * TOK, 0, lo, lx);
-        zip3_step<NT>(P, Q, C + (size_t)src * TOK, C + (size_t)src * TOK, arow, lo, lx);
-        ex += cex[src];
-#pragma unroll
-        for (int K = 0; K < NT; ++K)
-#pragma unroll
-            for (int J = 0; J < NT; ++J) P[K][J] = Q[K][J];
-        zip3_rescale<NT>(P, ex);
-    }
+    // ---- fold the workgroup's segments into one (zip3_fold): the operator table is dead once every wavefront is
+    // here; its space becomes the exchange area ----
+    zip3_fold<NT, true>(P, ex, C, cex, (int)blk.n, slot, tid >> 6, lo, lx);
 
     if (slot == 0) {
         const size_t gv = (size_t)b * a.n_vecs_total + blk.out_vec0;

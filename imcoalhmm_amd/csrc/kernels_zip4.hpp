@@ -133,18 +133,58 @@ __global__ __launch_bounds__(64) void k_z4_level(BigArgs a, int first, int count
 // idle entries), which keeps the three phases wavefront-uniform; a mixed wavefront is still correct (a child that
 // needs no recomputing is "recomputed" as child x identity, which is exact).
 // Saves a kernel boundary (~4.9 us) per pair of depths for ~1.5-3 us of extra products: 12 -> 7 launches at 4096 tokens.
-template <int NT>
-__global__ __launch_bounds__(64) void k_z4_level2(BigArgs a, const int4 *desc2, int first, int count)
+// FIRST = true: the evaluation's first launch (depths 1 and 2).  Every leaf of those tokens is a raw symbol or the
+// identity, so the wavefront builds the S raw operators C_s = diag(E[:,s]) T' (and the identity) itself, in LDS, straight
+// from the caller's parameters - `params_src` is the device-visible alias of the mapped staging slot on the host - and
+// never reads the table; workgroup 0 also writes the raw entries and the identity into the table and the parameters into
+// a.params for the launches that follow.  This replaces k_stage_params + k_z4_raw + the two host-paced gaps between
+// three very short kernels (rocprofv3 timeline, profiles/r03_trace_config1.txt: 3.4 + 4.0 + 2.4 + 3.8 us).
+template <int NT, bool FIRST>
+__global__ __launch_bounds__(64) void k_z4_level2(BigArgs a, const int4 *desc2, int first, int count, const double *params_src)
 {
     using Geo = Zip3Geom<NT>;
-    constexpr int TOK = Geo::TOK;
+    constexpr int TOK = Geo::TOK, NP = Geo::NP;
     __shared__ __attribute__((aligned(16))) double turn[4 * TOK];          // one entry per MFMA block: D layout in, A rows out
+    extern __shared__ __attribute__((aligned(16))) double rawtab[];        // FIRST: the parameter set (a.pstride doubles)
     const int b = blockIdx.y, lane = threadIdx.x;
     const int q = lane >> 4, bq = (lane >> 2) & 3, r = lane & 3;
     const int lo = (q * 4 + r) * Geo::NTE, lx = q * 4 + r;
     double *Gt = a.Ctab + (size_t)b * (a.A + 1) * TOK;
     int *Gc = a.cex + (size_t)b * (a.A + 1);
     const int IDENT = a.A;
+    if constexpr (FIRST) {
+        const double *src = params_src + (size_t)b * a.pstride;
+        double *lp = rawtab;                                               // a.pstride doubles (even)
+        // (all of a lane's loads in flight together: `src` is host memory, ~2 us per round trip over PCIe)
+        for (int k0 = 0; k0 < (int)a.pstride; k0 += 8 * 128) {
+            double2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * 128 + lane * 2;
+                v[u] = k < (int)a.pstride ? *reinterpret_cast<const double2 *>(src + k) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * 128 + lane * 2;
+                if (k < (int)a.pstride) *reinterpret_cast<double2 *>(lp + k) = v[u];
+            }
+        }
+        wave_fence();
+        if (blockIdx.x == 0) {                                            // (wavefront-uniform)
+            double *dp = const_cast<double *>(a.params) + (size_t)b * a.pstride;
+            for (int k = lane * 2; k < (int)a.pstride; k += 128) *reinterpret_cast<double2 *>(dp + k) = *reinterpret_cast<const double2 *>(lp + k);
+        }
+        // the table's raw entries and the identity, dealt over the launch's workgroups (later launches read them)
+        const double *Tp = lp + a.PP, *Etg = lp + a.PP + (size_t)a.PP * a.PP;
+        for (int s = blockIdx.x; s <= a.S; s += gridDim.x) {
+            double *Gz = Gt + (size_t)(s < a.S ? s : IDENT) * TOK;
+            for (int idx = lane; idx < NP * NP; idx += 64) {
+                const int i = idx / NP, j = idx - i * NP;
+                Gz[Geo::idx(i, j)] = s < a.S ? Etg[(size_t)s * a.PP + i] * Tp[(size_t)j * a.PP + i] : (i == j ? 1.0 : 0.0);
+            }
+            if (lane == 0) Gc[s < a.S ? s : IDENT] = 0;
+        }
+    }
     const int ti = blockIdx.x * 4 + bq;
     int4 d0 = ti < count ? desc2[2 * (first + ti)] : make_int4(-1, 0, 0, 0);
     int4 d1 = ti < count ? desc2[2 * (first + ti) + 1] : make_int4(0, 0, 0, 0);
@@ -154,20 +194,39 @@ __global__ __launch_bounds__(64) void k_z4_level2(BigArgs a, const int4 *desc2, 
     const bool needL = (d0.w & 1) != 0, needR = (d0.w & 2) != 0;
     const bool anyL = __any(needL), anyR = __any(needR);              // wavefront-uniform
 
+    // a leaf operand: its table entry; in the first launch every leaf is a raw symbol's operator C_s[i][j] = E[s][i] T[j][i]
+    // or the identity, formed on the fly from the parameters in LDS
+    const double *lp = rawtab;
+    auto leaf = [&](int tok, int i, int j) __attribute__((always_inline)) {
+        const double *Tp = lp + a.PP, *Etg = lp + a.PP + (size_t)a.PP * a.PP;
+        const double v = Etg[(size_t)(tok == IDENT ? 0 : tok) * a.PP + i] * Tp[(size_t)j * a.PP + i];
+        return tok == IDENT ? (i == j ? 1.0 : 0.0) : v;
+    };
+    auto expo = [&](int tok) __attribute__((always_inline)) { if constexpr (FIRST) return 0; else return Gc[tok]; };
     auto load_B = [&](double (&Bt)[NT][NT], int tok) __attribute__((always_inline)) {
         const double *G = Gt + (size_t)tok * TOK;
 #pragma unroll
         for (int K = 0; K < NT; ++K)
 #pragma unroll
-            for (int J = 0; J < NT; ++J) Bt[K][J] = G[Geo::idx(4 * K + q, 4 * J + r)];
+            for (int J = 0; J < NT; ++J) {
+                if constexpr (FIRST) Bt[K][J] = leaf(tok, 4 * K + q, 4 * J + r);
+                else Bt[K][J] = G[Geo::idx(4 * K + q, 4 * J + r)];
+            }
     };
-    auto load_A = [&](double (&Ar)[NT][NT], int tok) __attribute__((always_inline)) {
+    auto load_A = [&](double (&Ar)[NT][NT], int tok) __attribute__((always_inline)) {     // Ar[I][K] = C[4I + r][4K + q]
         const double *G = Gt + (size_t)tok * TOK;
 #pragma unroll
-        for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(Ar[I], G, I, lo, lx);
+        for (int I = 0; I < NT; ++I) {
+            if constexpr (FIRST) {
+#pragma unroll
+                for (int K = 0; K < NT; ++K) Ar[I][K] = leaf(tok, 4 * I + r, 4 * K + q);
+            } else zip4_load_row_global<NT>(Ar[I], G, I, lo, lx);
+        }
     };
 
     // ---- left child as the B operand ----
+    // (hoisting the right child's loads above the left child's 125 MFMAs was tried in round 3: 324 registers, one
+    // wavefront per SIMD, launches 7.4-10.4 us instead of 6.8-9.4 - no gain)
     double L[NT][NT];
     int eL;
     if (anyL) {
@@ -175,11 +234,11 @@ __global__ __launch_bounds__(64) void k_z4_level2(BigArgs a, const int4 *desc2, 
         double Bt[NT][NT], Ar[NT][NT];
         load_B(Bt, t0);
         load_A(Ar, t1);
-        eL = Gc[t0] + Gc[t1];
+        eL = expo(t0) + expo(t1);
         zip4_step_regs<NT>(Bt, L, Ar);
     } else {
         load_B(L, zl);
-        eL = Gc[zl];
+        eL = expo(zl);
     }
     // ---- right child as A operand rows ----
     double R[NT][NT];
@@ -189,7 +248,7 @@ __global__ __launch_bounds__(64) void k_z4_level2(BigArgs a, const int4 *desc2, 
         double Bt[NT][NT], Ar[NT][NT], Out[NT][NT];
         load_B(Bt, t0);
         load_A(Ar, t1);
-        eR = Gc[t0] + Gc[t1];
+        eR = expo(t0) + expo(t1);
         zip4_step_regs<NT>(Bt, Out, Ar);
         double *mine = turn + bq * TOK;
 #pragma unroll
@@ -201,7 +260,7 @@ __global__ __launch_bounds__(64) void k_z4_level2(BigArgs a, const int4 *desc2, 
         for (int I = 0; I < NT; ++I) zip3_load_row<NT>(R[I], mine, I, lo, lx);
     } else {
         load_A(R, zr);
-        eR = Gc[zr];
+        eR = expo(zr);
     }
     // ---- the token itself ----
     double Out[NT][NT];
@@ -215,6 +274,132 @@ __global__ __launch_bounds__(64) void k_z4_level2(BigArgs a, const int4 *desc2, 
 #pragma unroll
             for (int J = 0; J < NT; ++J) Gz[Geo::idx(4 * K + q, 4 * J + r)] = Out[K][J];
         if (q == 0 && r == 0) Gc[z] = eL + eR + e2;
+    }
+}
+
+// THREE dictionary depths per launch (k_z4_level3): one WAVEFRONT per token.  A token of depths D+1 .. D+3 is the ordered
+// product of at most eight entries of depth <= D (its children, grandchildren or great-grandchildren - whichever are
+// already in the table; the host lists them as the eight leaves of a complete binary tree, padded with the identity:
+// a ready node sits in the first leaf of its range).  The wavefront's four MFMA blocks form the four leaf pairs at once,
+// then fold 1 -> 0 and 3 -> 2, then 2 -> 0 through LDS (zip3_fold's in-wavefront stage): three dependent steps for three
+// depths, where k_z4_level2 spends three dependent products on two.  The bracketing is the dictionary's own, and
+// powers of two scale exactly, so every entry has the bits the one-depth-per-launch build gives it.
+// FIRST: the evaluation's first launch - every leaf is a raw symbol's operator or the identity, formed on the fly from
+// the parameters, which the workgroup fetches from the caller's mapped staging slot (see k_z4_level2<., true>).
+constexpr int Z4L3_WAVES = 2;       // wavefronts (= tokens) per workgroup: 32 KB of exchange areas at N = 20, five workgroups per CU
+template <int NT>
+struct Z4L3Geom {
+    static constexpr int AREAS = Z4L3_WAVES * 4 + 2;
+    static constexpr size_t PARAMS_AT = (size_t)AREAS * Zip3Geom<NT>::TOK + ((AREAS + 3) / 4) * 2;   // doubles, 16-byte aligned
+    static constexpr size_t lds_bytes(size_t pstride) { return (PARAMS_AT + pstride) * 8; }
+};
+template <int NT, bool FIRST>
+__global__ __launch_bounds__(Z4L3_WAVES * 64, 3) void k_z4_level3(BigArgs a, const int4 *desc3, int first, int count, const double *params_src)
+{
+    using Geo = Zip3Geom<NT>;
+    constexpr int TOK = Geo::TOK, NP = Geo::NP, THREADS = Z4L3_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) double l3lds[];         // [waves][4][TOK] exchange areas | [waves][4] ints | FIRST: parameters
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int q = lane >> 4, bq = (lane >> 2) & 3, r = lane & 3;
+    const int lo = (q * 4 + r) * Geo::NTE, lx = q * 4 + r;
+    double *Gt = a.Ctab + (size_t)b * (a.A + 1) * TOK;
+    int *Gc = a.cex + (size_t)b * (a.A + 1);
+    const int IDENT = a.A;
+    // (two spare areas: zip3_fold's idle blocks read - and discard - up to two areas beyond their wavefront's four)
+    double *X = l3lds + (size_t)wv * 4 * TOK;
+    int *xe = reinterpret_cast<int *>(l3lds + (size_t)Z4L3Geom<NT>::AREAS * TOK) + wv * 4;
+    const double *lp = l3lds + Z4L3Geom<NT>::PARAMS_AT;                   // FIRST: a.pstride doubles behind the ints
+    if constexpr (FIRST) {
+        const double *src = params_src + (size_t)b * a.pstride;
+        double *lpw = const_cast<double *>(lp);
+        // (all of a lane's loads in flight together: `src` is host memory, ~2 us per round trip over PCIe)
+        for (int k0 = 0; k0 < (int)a.pstride; k0 += 2 * 2 * THREADS) {
+            double2 v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = k0 + (u * THREADS + tid) * 2;
+                v[u] = k < (int)a.pstride ? *reinterpret_cast<const double2 *>(src + k) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = k0 + (u * THREADS + tid) * 2;
+                if (k < (int)a.pstride) *reinterpret_cast<double2 *>(lpw + k) = v[u];
+            }
+        }
+        __syncthreads();
+        if (blockIdx.x == 0) {
+            double *dp = const_cast<double *>(a.params) + (size_t)b * a.pstride;
+            for (int k = tid * 2; k < (int)a.pstride; k += 2 * THREADS) *reinterpret_cast<double2 *>(dp + k) = *reinterpret_cast<const double2 *>(lp + k);
+        }
+        // the table's raw entries and the identity, dealt over the launch's workgroups (later launches read them)
+        const double *Tp = lp + a.PP, *Etg = lp + a.PP + (size_t)a.PP * a.PP;
+        for (int s = blockIdx.x; s <= a.S; s += gridDim.x) {
+            double *Gz = Gt + (size_t)(s < a.S ? s : IDENT) * TOK;
+            for (int idx = tid; idx < NP * NP; idx += THREADS) {
+                const int i = idx / NP, j = idx - i * NP;
+                Gz[Geo::idx(i, j)] = s < a.S ? Etg[(size_t)s * a.PP + i] * Tp[(size_t)j * a.PP + i] : (i == j ? 1.0 : 0.0);
+            }
+            if (tid == 0) Gc[s < a.S ? s : IDENT] = 0;
+        }
+    }
+    const int ti = blockIdx.x * Z4L3_WAVES + wv;                          // (wavefront-uniform)
+    if (ti >= count) return;
+    const int4 d0 = desc3[3 * (first + ti)], d1 = desc3[3 * (first + ti) + 1], d2 = desc3[3 * (first + ti) + 2];
+    const int z = d0.x;
+    const int leaves[8] = {d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x};
+    int t0 = leaves[0], t1 = leaves[1];                                   // this block's pair: leaves 2 bq, 2 bq + 1
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { t0 = bq == k ? leaves[2 * k] : t0; t1 = bq == k ? leaves[2 * k + 1] : t1; }
+    auto leaf = [&](int tok, int i, int j) __attribute__((always_inline)) {
+        const double *Tp = lp + a.PP, *Etg = lp + a.PP + (size_t)a.PP * a.PP;
+        const double v = Etg[(size_t)(tok == IDENT ? 0 : tok) * a.PP + i] * Tp[(size_t)j * a.PP + i];
+        return tok == IDENT ? (i == j ? 1.0 : 0.0) : v;
+    };
+    double Bt[NT][NT], P[NT][NT];
+    int ex;
+    {
+        const double *G0 = Gt + (size_t)t0 * TOK, *G1 = Gt + (size_t)t1 * TOK;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                if constexpr (FIRST) Bt[K][J] = leaf(t0, 4 * K + q, 4 * J + r);
+                else Bt[K][J] = G0[Geo::idx(4 * K + q, 4 * J + r)];
+            }
+        if constexpr (FIRST) ex = 0;
+        else ex = Gc[t0] + Gc[t1];
+        // P = C_t1 * C_t0, the A operand's tile-rows one row ahead of their use (ten registers instead of fifty)
+        auto row = [&](double (&av)[NT], int I) __attribute__((always_inline)) {
+            if constexpr (FIRST) {
+#pragma unroll
+                for (int K = 0; K < NT; ++K) av[K] = leaf(t1, 4 * I + r, 4 * K + q);
+            } else zip4_load_row_global<NT>(av, G1, I, lo, lx);
+        };
+        double av[NT], an[NT];
+        row(av, 0);
+#pragma unroll
+        for (int I = 0; I < NT; ++I) {
+            if (I + 1 < NT) row(an, I + 1);
+#pragma unroll
+            for (int K = 0; K < NT; ++K)
+#pragma unroll
+                for (int J = 0; J < NT; ++J)
+                    P[I][J] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[K], Bt[K][J], K == 0 ? 0.0 : P[I][J], 0, 0, 0);
+#pragma unroll
+            for (int K = 0; K < NT; ++K) av[K] = an[K];
+        }
+    }
+    // (no rescale between the three levels: products of a few normalised operators stay far inside the exponent range,
+    // and powers of two scale exactly - the entry's bits are those of the one-depth-per-launch build)
+    zip3_fold<NT, false, false>(P, ex, X, xe, 4, bq, 0, lo, lx);          // 1 -> 0, 3 -> 2, then 2 -> 0
+    zip3_rescale<NT>(P, ex);
+    if (bq == 0) {
+        double *Gz = Gt + (size_t)z * TOK;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) Gz[Geo::idx(4 * K + q, 4 * J + r)] = P[K][J];
+        if (q == 0 && r == 0) Gc[z] = ex;
     }
 }
 
@@ -478,40 +663,9 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024 && blockIdx.y == 0) g_z4_dbg[1024 * 8 + blockIdx.x * 8 + (threadIdx.x >> 6)] = wall_clock64();
 #endif
 
-    // ---- fold the workgroup's segments into one (k_zpropagate3's fold: LDS entries become the exchange area) ----
-    for (int stride = 1; stride < Z2SLOTS; stride <<= 1) {
-        if ((int)blk.n <= stride) break;          // workgroup-uniform
-        __syncthreads();                          // table (or previous level's exchange data) no longer read
-        if (stride == 1) {
-            for (int idx = tid; idx < NP * NP; idx += THREADS) {
-                const int i = idx / NP, j = idx - i * NP;
-                C[(size_t)Z2SLOTS * TOK + Geo::idx(i, j)] = i == j ? 1.0 : 0.0;
-            }
-            if (tid == 0) xex[Z2SLOTS] = 0;
-        }
-        if (valid && (slot & stride) && !(slot & (stride - 1))) {   // this slot is a partner ("hi") at this level
-            double *dst = C + (size_t)slot * TOK;
-#pragma unroll
-            for (int K = 0; K < NT; ++K)
-#pragma unroll
-                for (int J = 0; J < NT; ++J) dst[Geo::idx(4 * K + q, 4 * J + r)] = P[K][J];
-            if (q == 0 && r == 0) xex[slot] = ex;
-        }
-        __syncthreads();
-        const bool act = valid && !(slot & (2 * stride - 1)) && slot + stride < (int)blk.n;
-        const int src = act ? slot + stride : Z2SLOTS;
-        zip3_load_row<NT>(al, C + (size_t)src * TOK, 0, lo, lx);
-        zip3_step<NT>(P, Q, C + (size_t)src * TOK, C + (size_t)src * TOK, al, lo, lx);
-        ex += xex[src];
-#pragma unroll
-        for (int K = 0; K < NT; ++K)
-#pragma unroll
-            for (int J = 0; J < NT; ++J) P[K][J] = Q[K][J];
-        zip3_rescale<NT>(P, ex);
-#ifdef IMC_Z4_TIMING
-        if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.y == 0) g_z4_dbg[2 * 1024 * 8 + blockIdx.x * 8 + (31 - __clz(stride))] = wall_clock64();
-#endif
-    }
+    // ---- fold the workgroup's segments into one (zip3_fold; the LDS entries become the exchange area; the streamed
+    // form keeps nothing in LDS during the scan, so its wavefronts start folding as they finish) ----
+    zip3_fold<NT, HYB>(P, ex, C, xex, (int)blk.n, slot, tid >> 6, lo, lx);
 
     Z4_STAMP(5);
 #ifdef IMC_Z4_TIMING

@@ -229,6 +229,14 @@ AB_SWITCHES = textwrap.dedent('''
         assert "k_zpropagate4" in _capi.last_plan()["kernels"]
         out += [float(x).hex() for x in v.ravel()]
         _capi.check(L.imc_dictionary_reset())
+    # a small launch of the LDS-table kernel (<= 32 workgroups: each fetches the parameter set itself, or k_stage_params does)
+    _capi.check(L.imc_set_compression(1)); _capi.check(L.imc_set_blocked_kernel(4))
+    for n in (10, 20):
+        h = synth.random_hmm(n, 3, seed=70 + n, stay=0.995)
+        f = Forwarder.from_array(synth.sample_alignment(*h, 65_255, seed=n), 3)
+        out.append(float(f.forward(*h)).hex())
+        assert "k_zpropagate3" in _capi.last_plan()["kernels"]
+        _capi.check(L.imc_dictionary_reset())
     # mat-vec chain at 150 states (packed or padded operator table), and the hand-off tails of a long chunk
     _capi.check(L.imc_set_compression(1)); _capi.check(L.imc_set_blocked_kernel(4))
     h150 = synth.random_hmm(150, 3, seed=7, stay=0.5)
@@ -245,16 +253,20 @@ AB_SWITCHES = textwrap.dedent('''
 
 def test_ab_switches_change_nothing_but_the_schedule(tmp_path):
     """The launch-schedule switches of the header (IMC_TABLE_PAIRS: two dictionary depths per table launch with the
-    second depth's children recomputed; IMC_PACK_TABLE: the mat-vec chain reads a packed copy of the operator table)
+    second depth's children recomputed; IMC_PACK_TABLE: the mat-vec chain reads a packed copy of the operator table;
+    IMC_FUSE_HEAD: the first table launch fetches the parameters and builds the raw operators itself; IMC_TABLE_TRIPLES:
+    three depths per table launch, one wavefront per token)
     re-associate nothing: every value must come out bit for bit the same with the switch on and off.  (Own processes:
     the switches are read when the library's context is created.)"""
     script = tmp_path / "ab.py"
     script.write_text(AB_SWITCHES)
     outs = {}
-    for pairs, pack in ((1, 1), (0, 1), (1, 0)):
-        env = dict(os.environ, IMC_TABLE_PAIRS=str(pairs), IMC_PACK_TABLE=str(pack))
+    combos = ((1, 1, 1, 1), (0, 1, 1, 1), (1, 0, 1, 1), (1, 1, 0, 1), (1, 1, 1, 0), (1, 1, 0, 0))
+    for pairs, pack, fuse, triples in combos:
+        env = dict(os.environ, IMC_TABLE_PAIRS=str(pairs), IMC_PACK_TABLE=str(pack), IMC_FUSE_HEAD=str(fuse),
+                   IMC_TABLE_TRIPLES=str(triples))
         r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
-        outs[(pairs, pack)] = r.stdout.strip().splitlines()[-1]
-    assert outs[(1, 1)] == outs[(0, 1)] == outs[(1, 0)], outs
-    assert "k_big_vector" in outs[(1, 1)] and "k_big_propagate" in outs[(1, 1)]      # both large-N paths were on the route
+        outs[(pairs, pack, fuse, triples)] = r.stdout.strip().splitlines()[-1]
+    assert len(set(outs.values())) == 1, outs
+    assert "k_big_vector" in outs[combos[0]] and "k_big_propagate" in outs[combos[0]]      # both large-N paths were on the route
