@@ -140,6 +140,9 @@ struct Ctx {
     bool table_pairs = true;  // IMC_TABLE_PAIRS=0: k_zpropagate4's table one dictionary depth per launch (A/B measurements)
     bool table_triples = false; // IMC_TABLE_TRIPLES=1: three depths per launch, one wavefront per token (k_z4_level3) - measured no
                                // faster than pairs (54 vs 52.5 us at 4096 tokens: 2197 wavefronts in the depth 7-9 launch), kept for A/B
+    int fuse_tail = 1;        // the chunk's last workgroup finishes the chunk (zip3_tail) instead of k_chain launches: 1 = where a chunk is
+                              // at most four workgroups (one in-wavefront fold; measured: 100 x 1e6 columns -1.5 us, and +6 us at 13
+                              // workgroups of 20 states, where the chain's twenty parallel wavefronts win), 2 = wherever possible, 0 = never (IMC_FUSE_TAIL)
     bool fuse_head = true;    // IMC_FUSE_HEAD=0: k_stage_params + k_z4_raw as launches of their own (A/B measurements)
     bool pack_table = true;   // IMC_PACK_TABLE=0: the mat-vec chain reads the padded table (A/B measurements)
     bool guard = false;       // IMC_GUARD=1: every device buffer ends flush against an unmapped guard range (dev_alloc)
@@ -190,6 +193,7 @@ int ensure_ctx()
     if (const char *tp = std::getenv("IMC_TABLE_PAIRS")) g.table_pairs = std::atoi(tp) != 0;
     if (const char *fh = std::getenv("IMC_FUSE_HEAD")) g.fuse_head = std::atoi(fh) != 0;
     if (const char *tt = std::getenv("IMC_TABLE_TRIPLES")) g.table_triples = std::atoi(tt) != 0;
+    if (const char *ft = std::getenv("IMC_FUSE_TAIL")) g.fuse_tail = std::max(0, std::min(2, std::atoi(ft)));
     if (const char *zs = std::getenv("IMC_Z4_STREAM")) { const int v = std::atoi(zs); if (v >= -1 && v <= 1) g.z4_stream = v; }
     g.pid = me;
     g.ready = true;
@@ -203,7 +207,10 @@ int ensure_ctx()
 // silently touching whatever the allocator happened to place next (tests/test_gpu_guard.py runs the create / free /
 // compression-flip / create sequence of round 1's unexplained fault this way).
 struct GuardRec { hipDeviceptr_t va; size_t va_size; hipMemGenericAllocationHandle_t handle; hipDeviceptr_t map; size_t map_size; };
-std::map<void *, GuardRec> g_guard;
+// (never destroyed: the context `g` - whose dictionaries free device buffers in their destructors - outlives every
+// other static at process exit, and dev_free must still find the guard records then; a plain static map is destroyed
+// first and the lookup walked freed nodes: "malloc_consolidate(): invalid chunk size" at exit under IMC_GUARD=1)
+std::map<void *, GuardRec> &g_guard = *new std::map<void *, GuardRec>();
 
 hipError_t dev_alloc(void **p, size_t bytes)
 {
@@ -247,7 +254,11 @@ void dev_free(void *p)
     (void)hipDeviceSynchronize();
     (void)hipMemUnmap(it->second.map, it->second.map_size);
     (void)hipMemRelease(it->second.handle);
-    (void)hipMemAddressFree(it->second.va, it->second.va_size);
+    // The address range is NOT given back (hipMemAddressFree): a freed guard buffer stays unmapped for the rest of the
+    // process, so a use after free faults too - and no later buffer can be mapped at an address some CU may still hold a
+    // translation for.  (Round 3: with the ranges recycled, a Forwarder created right after another had been freed
+    // sometimes evaluated to a wrong value in every plan - 3 of 4 processes, under IMC_GUARD=1 only, never with hipMalloc -
+    // and a later launch faulted at an address nobody had computed; with the ranges kept, neither was seen again.)
     g_guard.erase(it);
 }
 
@@ -606,6 +617,12 @@ struct Group {             // one propagate launch
     int4 *d_tab_desc = nullptr;               // hybrid table: {token, left, right, 0} per entry of the depth order
     int4 *d_tab_desc2 = nullptr;              // ... two int4 per entry of the two-depths-per-launch schedule (k_z4_level2)
     std::vector<std::pair<int, int>> tab2;    // ... (first entry, entries) per launch
+    // fused tail (zip3_tail): per workgroup {chunk, unit, units of the chunk}; published operators, exponents, arrival counters
+    std::vector<Z2Tail> tails;
+    Z2Tail *d_tails = nullptr;
+    double *d_tailX = nullptr;
+    int *d_tailE = nullptr, *d_tail_arrive = nullptr;
+    int tail_stride = 0;
     int4 *d_tab_desc3 = nullptr;              // ... three int4 per token of the three-depths-per-launch schedule (k_z4_level3): {token, leaves 0-2}, {leaves 3-6}, {leaf 7}
     std::vector<std::pair<int, int>> tab3;
     std::vector<int> tab_lvl;                 // host copy of the depth offsets
@@ -687,7 +704,7 @@ struct Plan {
         if (graph) (void)hipGraphExecDestroy(graph);
         dev_free(d_segs); dev_free(d_vecs); dev_free(d_final_vec);
         for (auto &l : levels) l.release();
-        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_desc2); dev_free(gr.d_tab_desc3); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_Cpack); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
+        for (auto &gr : groups) { dev_free(gr.d_seg_ids); dev_free(gr.d_seg_out); dev_free(gr.d_blocks); dev_free(gr.d_hot); dev_free(gr.d_tab_desc); dev_free(gr.d_tab_desc2); dev_free(gr.d_tab_desc3); dev_free(gr.d_tails); dev_free(gr.d_tailX); dev_free(gr.d_tailE); dev_free(gr.d_tail_arrive); dev_free(gr.d_tab_order); dev_free(gr.d_tab_lvl); dev_free(gr.d_big_blocks); dev_free(gr.d_Ctab); dev_free(gr.d_Cpack); dev_free(gr.d_cex); dev_free(gr.d_tail_blocks); dev_free(gr.d_r1flag); dev_free(gr.d_r1at); dev_free(gr.d_r1u); dev_free(gr.d_r1alpha); }
         dev_free(d_params); dev_free(d_out);
         for (int k = 0; k < 2; ++k) { (void)hipHostFree(h_params[k]); if (ev_params[k]) (void)hipEventDestroy(ev_params[k]); }
         (void)hipHostFree(h_out);
@@ -1128,6 +1145,23 @@ struct PlanBuilder {
             }
             gr.n_vecs = (uint32_t)vecs.size() - gr.vec_begin;
         }
+        // fused tail: one blocked-MFMA group holds every chunk, no chunk is empty or longer than Z2SLOTS workgroups
+        if (p->groups.size() == 1 && p->groups[0].zip2 && kc->use3() && !op_mode && n_chunks > 0) {
+            Group &gr = p->groups[0];
+            bool ok = true;
+            size_t most = 0;
+            for (int f = 0; f < n_chunks; ++f) {
+                ok = ok && !chunk_units[f].empty() && chunk_units[f].size() <= (size_t)Z2SLOTS;
+                most = std::max(most, chunk_units[f].size());
+            }
+            if (ok) {
+                for (int f : gr.chunks)
+                    for (size_t u = 0; u < chunk_units[f].size(); ++u)
+                        gr.tails.push_back(Z2Tail{(uint32_t)f, (uint32_t)u, (uint32_t)chunk_units[f].size(), 0u});
+                gr.tail_stride = (int)most;
+                if (gr.tails.size() != gr.blocks.size()) gr.tails.clear();      // (cannot happen: one entry per workgroup)
+            }
+        }
         if (vecs.size() >= (size_t)UINT32_MAX / 2) return fail(IMC_ERR_ARG, "too many vectors in one call");
         p->n_segs = (uint32_t)segs.size();
         p->n_vecs = (uint32_t)vecs.size();
@@ -1231,6 +1265,13 @@ struct PlanBuilder {
         }
         for (Group &gr : q->groups) {
             if (gr.zip2 && e == hipSuccess) e = up((void **)&gr.d_blocks, gr.blocks.data(), gr.blocks.size() * sizeof(Z2Block));
+            if (!gr.tails.empty() && e == hipSuccess) {
+                const size_t slots = (size_t)B * n_chunks * gr.tail_stride;
+                e = up((void **)&gr.d_tails, gr.tails.data(), gr.tails.size() * sizeof(Z2Tail));
+                if (e == hipSuccess) e = dev_alloc((void **)&gr.d_tailX, slots * kc->tok_doubles * 8);
+                if (e == hipSuccess) e = dev_alloc((void **)&gr.d_tailE, slots * 128);
+                if (e == hipSuccess) e = zalloc((void **)&gr.d_tail_arrive, (size_t)B * n_chunks * 4);
+            }
             if (gr.zip4 && e == hipSuccess) {
                 // hot set: the most frequent tokens of this group's chunks, as many as LDS holds beside the identity
                 std::vector<uint64_t> cnt((size_t)gr.A, 0);
@@ -1499,7 +1540,7 @@ int stage_params(Plan *p, const double *pis, const double *Ts, const double *Es,
 // Enqueue one batch evaluation on `stream`: parameter upload, propagate, stitch.  Per-chunk results are written
 // to `out` ([B][n_chunks]; device memory or mapped pinned host memory).  Contains no synchronisation, so the
 // same call sequence can be captured into a hipGraph.
-int enqueue(Plan *p, hipStream_t stream, double *out)
+int enqueue(Plan *p, hipStream_t stream, double *out, bool allow_tail = true)
 {
     KernelChoice *kc = p->kc;
     const int N = p->N, S = p->S, NP = kc->NP, B = p->B;
@@ -1549,6 +1590,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
     bool a_recorded = false;
     if (prof) { HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b)); HIP_TRY(hipEventCreate(&ev.c)); }
 #define IMC_MARK_A() do { if (prof && !a_recorded) { HIP_TRY(hipEventRecord(ev.a, stream)); a_recorded = true; } } while (0)
+    bool tail_used = false;             // the propagate launch finishes the chunks itself (zip3_tail): no stitch launches
     p->kernels.clear();
     auto note = [&](const std::string &k) { p->kernels += (p->kernels.empty() ? "" : "+") + k; };
     for (const Group &gr : p->groups) {
@@ -1562,6 +1604,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
         a.A = gr.A; a.tok_left = gr.zip ? gr.dict->d_left : nullptr; a.tok_right = gr.zip ? gr.dict->d_right : nullptr;
         if (gr.big) {
             BigArgs ba;
+            ba.tail = nullptr; ba.tailX = nullptr; ba.tailE = nullptr; ba.tail_arrive = nullptr; ba.tail_out = nullptr; ba.tail_stride = 0; ba.n_chunks = p->n_chunks;
             ba.segs = p->d_segs; ba.seg_ids = gr.d_seg_ids; ba.seg_vec0 = gr.d_seg_out; ba.blocks = nullptr;
             ba.n_group_segs = (uint32_t)gr.seg_ids.size(); ba.n_vecs_total = p->n_vecs;
             ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.params_src = nullptr; ba.pstride = p->pstride; ba.PP = NP;
@@ -1646,6 +1689,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }
         } else if (gr.zip2) {
             BigArgs ba;
+            ba.tail = nullptr; ba.tailX = nullptr; ba.tailE = nullptr; ba.tail_arrive = nullptr; ba.tail_out = nullptr; ba.tail_stride = 0; ba.n_chunks = p->n_chunks;
             ba.segs = p->d_segs; ba.seg_ids = nullptr; ba.seg_vec0 = nullptr; ba.blocks = gr.d_blocks;
             ba.n_group_segs = (uint32_t)gr.blocks.size(); ba.n_vecs_total = p->n_vecs;
             ba.N = N; ba.S = S; ba.A = gr.A; ba.params = p->d_params; ba.params_src = nullptr; ba.pstride = p->pstride; ba.PP = NP;
@@ -1654,6 +1698,11 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
             ba.P = p->levels[0].d_P; ba.EX = p->levels[0].d_EX;
             ba.tab_order = gr.d_tab_order; ba.tab_lvl = gr.d_tab_lvl; ba.tab_nlvl = gr.tab_nlvl;
             ba.hot = gr.d_hot; ba.n_hot = gr.n_hot; ba.tab_desc = gr.d_tab_desc;
+            if (gr.d_tails && (g.fuse_tail == 2 || (g.fuse_tail == 1 && gr.tail_stride <= 4)) && allow_tail && kc->use3()) {
+                ba.tail = gr.d_tails; ba.tailX = gr.d_tailX; ba.tailE = gr.d_tailE; ba.tail_arrive = gr.d_tail_arrive;
+                ba.tail_out = out; ba.tail_stride = gr.tail_stride; ba.n_chunks = p->n_chunks;
+                tail_used = true;
+            }
             if (gr.zip4) {
                 // hybrid table: one workgroup per parameter set builds the operators in global memory (they stay in
                 // L2), then the scan caches the hot ones in LDS and streams the rest a step ahead
@@ -1758,7 +1807,8 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
     IMC_MARK_A();
 #undef IMC_MARK_A
     if (prof) HIP_TRY(hipEventRecord(ev.b, stream));
-    for (size_t l = 0; l + 1 < p->levels.size(); ++l) {
+    if (tail_used) note("fused-tail");
+    for (size_t l = 0; l + 1 < p->levels.size() && !tail_used; ++l) {
         const Level &in = p->levels[l], &ot = p->levels[l + 1];
         if (!in.n_segs || !ot.n_chains) continue;
         if (!kc->chain_self_emax) {   // (the single-wavefront chain kernels find the units' largest exponents themselves)
@@ -1773,7 +1823,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out)
                            ot.n_vecs, ot.d_P, ot.d_EX, (last_level && p->finish_fused) ? out : (double *)nullptr, p->n_chunks);
         HIP_TRY(hipGetLastError());
     }
-    if (p->n_chunks && !p->finish_fused) {
+    if (p->n_chunks && !p->finish_fused && !tail_used) {
         const Level &last = p->levels.back();
         hipLaunchKernelGGL(k_finish, dim3((p->n_chunks + 63) / 64, (unsigned)B), dim3(64), 0, stream,
                            p->d_final_vec, p->n_chunks, N, NP, last.n_vecs, last.d_P, last.d_EX, out);
@@ -1924,7 +1974,7 @@ int run_state(const imc_obs *const *chunks, int n_chunks, bool op_mode, int B, i
     Plan *p = nullptr;
     if (int rc = build_plan(chunks, n_chunks, N, S, B, op_mode, &p)) return rc;
     if (int rc = stage_params(p, pis, Ts, Es, g.use_graphs)) return rc;
-    if (int rc = enqueue(p, g.stream, p->d_out)) return rc;      // (the log-likelihoods are not read here)
+    if (int rc = enqueue(p, g.stream, p->d_out, false)) return rc;      // (the log-likelihoods are not read here; the state comes from the stitch levels)
     ++p->calls;
     for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
     g.last_kernels = p->kernels;

@@ -25,6 +25,8 @@ struct Z2Block {                  // one workgroup of k_zpropagate2: up to Z2SLO
     uint32_t first;               // 1: seg0 is its chunk's first segment -> the result is a vector
 };
 
+struct Z2Tail { uint32_t chunk, unit, n_units, pad; };
+
 struct BigArgs {
     const SegDesc *segs;          // all segments of the plan
     const uint32_t *seg_ids;      // k_big_propagate: segments of this launch group
@@ -66,6 +68,15 @@ struct BigArgs {
     // bytes and a padded row costs them ten cache lines instead of 9.4); written by the table kernels beside Ctab
     double *Cpack;
     int TS;
+    // fused tail of the blocked MFMA kernels (zip3_tail): every chunk of the launch is at most Z2SLOTS workgroups, each
+    // publishes its folded operator, and the chunk's LAST workgroup to arrive folds them and writes the chunk's
+    // log-likelihood - the evaluation has no stitch launches.  tail == nullptr: off.
+    const Z2Tail *tail;           // per workgroup: {chunk, unit within the chunk, units of the chunk}
+    double *tailX;                // [B][n_chunks][tail_stride][TOK] published operators (an LDS table entry's layout)
+    int *tailE;                   // [B][n_chunks][tail_stride][32] their exponents (one 128-byte line each)
+    int *tail_arrive;             // [B][n_chunks] arrival counters (zero between evaluations: the last arriver resets its own)
+    double *tail_out;             // [B][n_chunks] log-likelihoods (device memory or the mapped result slots on the host)
+    int tail_stride, n_chunks;
 };
 
 

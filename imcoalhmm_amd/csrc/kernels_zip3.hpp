@@ -197,6 +197,70 @@ __device__ __forceinline__ void zip3_fold(double (&P)[NT][NT], int &ex, double *
     }
 }
 
+// ---- fused tail: the chunk's workgroups meet, the last one to arrive finishes the chunk ----------------------------------
+// After zip3_fold slot 0 of a workgroup holds the product of its segments (the chunk's first workgroup: the forward
+// vector in column 0).  With at most Z2SLOTS workgroups per chunk the stitch is one more zip3_fold: every workgroup
+// publishes its operator in an LDS table entry's layout (sc1 stores: written through, the publishing wavefront drains
+// them with s_waitcnt vmcnt(0) before it signals), then adds one to the chunk's arrival counter (an agent-scope atomic);
+// the workgroup whose add returns n_units - 1 is the last: its 32 slots reload the chunk's operators (sc1 loads: past
+// this CU's L1; nobody on this XCD has read those lines before), fold them as the scan's own fold does, and slot 0
+// turns column 0 of the product into the chunk's log-likelihood, ln2 * exponent + log(sum), written straight to the
+// result slot.  (MI355X_MICROARCH.md, "Valid forms": one lane signals for all of its workgroup's stores, the consumer is
+// told by the value its own add returned, payload stores and loads all sc1.)  The counter is set back to zero by the
+// last arriver, so the next evaluation of the plan finds it clean.  A chunk of ONE workgroup skips the meeting.
+// Every published operator and every exponent sits on cache lines of its own (TOK * 8 is a multiple of 128 bytes, an
+// exponent has a 128-byte slot): a last arriver that shares an XCD with an earlier one must not find a line in that
+// L2 that was fetched before all of its words were written.
+template <int NT>
+__device__ __forceinline__ void zip3_tail(const BigArgs &a, double (&P)[NT][NT], int &ex, double *X, int *xe, int b, int slot, int lo, int lx)
+{
+    using Geo = Zip3Geom<NT>;
+    constexpr int TOK = Geo::TOK;
+    __shared__ int s_last;
+    const Z2Tail td = a.tail[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = lane >> 4, r = lane & 3;
+    const size_t cb = (size_t)b * a.n_chunks + td.chunk;
+    if (td.n_units > 1) {                                    // (workgroup-uniform)
+        if (slot == 0) {
+            double *dst = a.tailX + (cb * a.tail_stride + td.unit) * TOK;
+#pragma unroll
+            for (int K = 0; K < NT; ++K)
+#pragma unroll
+                for (int J = 0; J < NT; ++J)
+                    __hip_atomic_store(&dst[Geo::idx(4 * K + q, 4 * J + r)], P[K][J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q == 0 && r == 0) __hip_atomic_store(&a.tailE[(cb * a.tail_stride + td.unit) * 32], ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < 64) {                                      // wavefront 0 holds slot 0: it alone stored
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0)
+                s_last = __hip_atomic_fetch_add(&a.tail_arrive[cb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)td.n_units - 1;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const bool valid = slot < (int)td.n_units;
+        const double *src = a.tailX + (cb * a.tail_stride + (valid ? slot : 0)) * TOK;
+#pragma unroll
+        for (int K = 0; K < NT; ++K)
+#pragma unroll
+            for (int J = 0; J < NT; ++J) {
+                const double v = __hip_atomic_load(&src[Geo::idx(4 * K + q, 4 * J + r)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                P[K][J] = valid ? v : 0.0;
+            }
+        ex = __hip_atomic_load(&a.tailE[(cb * a.tail_stride + (valid ? slot : 0)) * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        zip3_fold<NT, true>(P, ex, X, xe, (int)td.n_units, slot, tid >> 6, lo, lx);
+        if (tid == 0) __hip_atomic_store(&a.tail_arrive[cb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (slot == 0) {
+        double part = 0.0;
+#pragma unroll
+        for (int K = 0; K < NT; ++K) part += (r == 0 && 4 * K + q < a.N) ? P[K][0] : 0.0;
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        if (lane == 0) a.tail_out[cb] = (double)ex * 0.693147180559945309417232121458 + log(part);
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigArgs a)
 {
@@ -405,4 +469,5 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
             }
         }
     }
+    if (a.tail) zip3_tail<NT>(a, P, ex, C, cex, b, slot, lo, lx);
 }

@@ -696,4 +696,5 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
             }
         }
     }
+    if (a.tail) zip3_tail<NT>(a, P, ex, C, xex, b, slot, lo, lx);
 }

@@ -9,7 +9,7 @@ for sub in ('fetch', 'write', 'sq', 'sq2', 'grbm'):
         k = row['Kernel_Name'].split('(')[0][:40]
         agg[k][row['Counter_Name']].append(float(row['Counter_Value']))
     for k, d in agg.items():
-        if 'propagate' in k or 'chain' in k or 'big_vector' in k:
+        if 'propagate' in k or 'chain' in k or 'big_vector' in k or 'k_z4_level' in k or 'table' in k:
             print(sub, k, {c: (len(v), sum(v)/len(v)) for c, v in d.items()})
 for f in glob.glob('%s/stats/*/*kernel_stats.csv' % base):
     print(open(f).read()[:1500])

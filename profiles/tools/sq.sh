@@ -4,8 +4,8 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; TAG=$1; shift
 export TMPDIR=/tmp; cd /tmp
 OUT=$R/gpurun_out/sq_$TAG; mkdir -p $OUT
-python3 $R/bench.py "$@" --no-cpu-baseline --no-extra --gen-workers 1 2>/dev/null | grep "^{" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$TAG', 'kernel_ms', d['roofline']['kernel_ms'], 'ms_per_step', d['ms_per_step'], d['roofline']['kernel'])"
-timeout -k 10 150 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/sq -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra --gen-workers 1 > $OUT/bench_sq.log 2>&1 || echo "sq run failed"
+python3 $R/bench.py "$@" --no-cpu-baseline --no-extra 2>/dev/null | grep "^{" | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$TAG', 'kernel_ms', d['roofline']['kernel_ms'], 'ms_per_step', d['ms_per_step'], d['roofline']['kernel'])"
+timeout -k 10 150 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d $OUT/sq -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra > $OUT/bench_sq.log 2>&1 || echo "sq run failed"
 python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

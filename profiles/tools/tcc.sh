@@ -4,8 +4,8 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; TAG=$1; shift
 export TMPDIR=/tmp; cd /tmp
 OUT=$R/gpurun_out/tcc_$TAG; mkdir -p $OUT
-timeout -k 10 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/tcc -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra --gen-workers 1 > $OUT/bench_tcc.log 2>&1 || echo "tcc run failed"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra --gen-workers 1 > $OUT/bench_stats.log 2>&1 || echo "stats run failed"
+timeout -k 10 400 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/tcc -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra > $OUT/bench_tcc.log 2>&1 || echo "tcc run failed"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py "$@" --no-cpu-baseline --no-extra > $OUT/bench_stats.log 2>&1 || echo "stats run failed"
 python3 - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -113,3 +113,57 @@ def test_create_free_flip_create_under_guard_pages(tmp_path):
     if "hipMemAddressReserve" in out.stderr or "hipMemCreate" in out.stderr or "hipMemGetAllocationGranularity" in out.stderr:
         pytest.skip("HIP virtual-memory management is unavailable on this box: %r" % (tail,))
     assert out.returncode == 0 and "sequence ok" in out.stdout and "families ok" in out.stdout and "raw-blocked ok" in out.stdout, tail
+
+
+TAIL_SCRIPT = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from imcoalhmm_amd import Forwarder, _capi, synth
+    from imcoalhmm_amd.hmm import forward_chunks_batch
+    from oracle import oracle_lib
+    oracle_lib.build()
+    L = _capi.lib()
+    d = np.load(os.path.join(%r, "tests", "golden", "hmm_params.npz"))
+    rng = np.random.default_rng(303)
+    used = 0
+    for case in range(14):
+        n = (7, 10, 12, 20, 24, 16, 4)[case %% 7]
+        B = 1 + case %% 3
+        if n in (10, 20):
+            hmms = [tuple(d["iso%%d_t%%d_%%s" %% (n, b %% 3, k)] for k in ("pi", "T", "E")) for b in range(B)]
+        else:
+            hmms = [synth.random_hmm(n, 3, seed=900 + case + b, stay=0.999) for b in range(B)]
+        pis, Ts, Es = (np.stack([h[k] for h in hmms]) for k in range(3))
+        lens = [40_000] + [int(x) for x in rng.integers(4_200, 60_000, size=case %% 5)]
+        chunks = [synth.sample_alignment(*hmms[0], m, seed=case * 10 + k) for k, m in enumerate(lens)]
+        for mode, variant in ((1, 4), (3, 3), (3, 5), (5, 3)):
+            L.imc_set_compression(mode); L.imc_set_blocked_kernel(variant); L.imc_dictionary_reset()
+            cs = [c[:7_000] for c in chunks] if mode == 5 else chunks    # (raw stream: one step per column)
+            fw = [Forwarder.from_array(c, 3) for c in cs]
+            for rep in range(2):                                   # twice: the arrival counters must be back at zero
+                per = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+                used += "fused-tail" in _capi.last_plan()["kernels"]
+                for b in range(B):
+                    for k, c in enumerate(cs):
+                        w = oracle_lib.forward_scaled(pis[b], Ts[b], Es[b], c)
+                        assert abs(per[b][k] - w) <= 1e-11 * abs(w), (case, mode, variant, rep, b, k, per[b][k], w)
+            del fw
+    assert used >= 40, used
+    print("tails ok", used, flush=True)
+''') % (REPO, REPO)
+
+
+def test_fused_tail_wherever_possible_under_guard_pages(tmp_path):
+    """The chunk's last workgroup finishes the chunk (zip3_tail: published operators, arrival counter, second fold) -
+    forced on for every plan that allows it (IMC_FUSE_TAIL=2; by default only chunks of at most four workgroups take
+    it), ragged multi-chunk batches, LDS-table / hybrid / raw-stream kernels, every evaluation twice, against the
+    oracle at 1e-11 and with every buffer flush against an unmapped page."""
+    script = tmp_path / "tail.py"
+    script.write_text(TAIL_SCRIPT)
+    env = dict(os.environ, IMC_GUARD="1", IMC_FUSE_TAIL="2")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
+    tail = (out.stdout[-1500:], out.stderr[-3000:])
+    if "hipMemAddressReserve" in out.stderr or "hipMemCreate" in out.stderr or "hipMemGetAllocationGranularity" in out.stderr:
+        pytest.skip("HIP virtual-memory management is unavailable on this box: %r" % (tail,))
+    assert out.returncode == 0 and "tails ok" in out.stdout, tail

@@ -219,6 +219,7 @@ AB_SWITCHES = textwrap.dedent('''
     from imcoalhmm_amd.hmm import forward_chunks_batch
     L = _capi.lib()
     out = []
+    tails = []
     # register-blocked MFMA kernel on a global table (two dictionary depths per table launch, or one)
     _capi.check(L.imc_set_compression(3)); _capi.check(L.imc_set_blocked_kernel(5))
     for n in (10, 20):
@@ -229,13 +230,22 @@ AB_SWITCHES = textwrap.dedent('''
         assert "k_zpropagate4" in _capi.last_plan()["kernels"]
         out += [float(x).hex() for x in v.ravel()]
         _capi.check(L.imc_dictionary_reset())
-    # a small launch of the LDS-table kernel (<= 32 workgroups: each fetches the parameter set itself, or k_stage_params does)
+    # small launches of the LDS-table kernel: <= 32 workgroups (each fetches the parameter set itself, or k_stage_params
+    # does), and chunks of at most 32 workgroups (the chunk's last workgroup can finish the chunk: IMC_FUSE_TAIL)
     _capi.check(L.imc_set_compression(1)); _capi.check(L.imc_set_blocked_kernel(4))
+    d = np.load(os.path.join(%r, "tests", "golden", "hmm_params.npz"))
     for n in (10, 20):
-        h = synth.random_hmm(n, 3, seed=70 + n, stay=0.995)
-        f = Forwarder.from_array(synth.sample_alignment(*h, 65_255, seed=n), 3)
-        out.append(float(f.forward(*h)).hex())
+        hmms = [tuple(d["iso%%d_t%%d_%%s" %% (n, b, k)] for k in ("pi", "T", "E")) for b in range(2)]
+        f = Forwarder.from_array(synth.sample_alignment(*hmms[0], 60_000, seed=n), 3)
+        out.append(float(f.forward(*hmms[0])).hex())
         assert "k_zpropagate3" in _capi.last_plan()["kernels"]
+        out.append(_capi.last_plan()["kernels"].replace("+fused-tail", ""))
+        tails.append("fused-tail" in _capi.last_plan()["kernels"])
+        fw = [f] + [Forwarder.from_array(synth.sample_alignment(*hmms[0], m, seed=n + k), 3) for k, m in enumerate((40_000, 5_000, 33_000))]
+        v = forward_chunks_batch([g.handle for g in fw], *(np.stack([h[k] for h in hmms]) for k in range(3)), per_chunk=True)
+        out += [float(x).hex() for x in v.ravel()]
+        tails.append("fused-tail" in _capi.last_plan()["kernels"])
+        del f, fw
         _capi.check(L.imc_dictionary_reset())
     # mat-vec chain at 150 states (packed or padded operator table), and the hand-off tails of a long chunk
     _capi.check(L.imc_set_compression(1)); _capi.check(L.imc_set_blocked_kernel(4))
@@ -247,8 +257,9 @@ AB_SWITCHES = textwrap.dedent('''
     long1 = Forwarder.from_array(synth.sample_alignment(*h150, 1_500_000, seed=3), 3)
     out.append(float(long1.forward(*h150)).hex())
     out.append(_capi.last_plan()["kernels"])
+    print("TAILS", "".join("1" if x else "0" for x in tails))
     print(" ".join(out))
-''') % (REPO,)
+''') % (REPO, REPO)
 
 
 def test_ab_switches_change_nothing_but_the_schedule(tmp_path):
@@ -270,3 +281,20 @@ def test_ab_switches_change_nothing_but_the_schedule(tmp_path):
         outs[(pairs, pack, fuse, triples)] = r.stdout.strip().splitlines()[-1]
     assert len(set(outs.values())) == 1, outs
     assert "k_big_vector" in outs[combos[0]] and "k_big_propagate" in outs[combos[0]]      # both large-N paths were on the route
+    # IMC_FUSE_TAIL (the chunk's last workgroup finishes the chunk instead of k_chain launches; 2 = wherever a chunk is at
+    # most 32 workgroups, 0 = never) re-associates the last few products and the final sum: same values to 1e-13, not
+    # the same bits
+    alt, used = {}, {}
+    for mode in ("0", "2"):
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(os.environ, IMC_FUSE_TAIL=mode))
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+        alt[mode] = r.stdout.strip().splitlines()[-1].split()
+        used[mode] = [l for l in r.stdout.splitlines() if l.startswith("TAILS")][-1].split()[1]
+    assert used["0"] == "0000" and used["2"] == "1111", used     # (the two routes really are different)
+    for other in alt.values():
+        for x, y in zip(outs[combos[0]].split(), other):
+            if x.startswith(("0x", "-0x")):
+                fx, fy = float.fromhex(x), float.fromhex(y)
+                assert abs(fx - fy) <= 1e-13 * abs(fx), (x, y)
+            else:
+                assert x == y
