@@ -861,9 +861,32 @@ struct PlanBuilder {
                             for (auto &pd : per_depth) passes += (pd.second + (int)Z2SLOTS - 1) / (int)Z2SLOTS;
                         }
                         const double nt = kc->NP / 4.0, t_step = std::max(0.25, 1.88 * nt * nt * nt / 125.0);
-                        const double steps = std::max(16.0, toks * B / ((double)g.cus * Z2SLOTS));
+                        // Time of the scan itself: workgroups of 32 segments are dealt PER CHUNK (a chunk of u workgroups is cut
+                        // into 32 u segments), and a launch of more workgroups than CUs runs in rounds, each paying the
+                        // workgroup's fixed part again.  rounds x (fixed + segment length x step) for the best number of rounds -
+                        // not tokens / slots: 100 chunks x 1e6 columns fill 78 % of one round or 98 % of two.
+                        double maxtok = 0.0;
+                        for (int f : kv.second) maxtok = std::max(maxtok, (double)chunks[f]->ntok[l]);
+                        // (up to 12 states two workgroups of the global-table kernel share a CU: twice the slots, 1.85x the step)
+                        const bool two_per_cu = !fits && kc->NP <= 12 && table_bytes <= Z4_STREAM_MAX_BYTES;
+                        const double n_ch = (double)kv.second.size(), slots = (double)g.cus * Z2SLOTS * (two_per_cu ? 2.0 : 1.0);
+                        auto scan_time = [&](double fixed_us, double step_us) {
+                            if (two_per_cu) step_us *= 1.85;
+                            double best_t = 1e300;
+                            for (int r = 1; r <= 6; ++r) {
+                                const double units = std::max(1.0, std::floor(slots * r / (n_ch * B) / Z2SLOTS));
+                                const double seg = std::max(16.0, std::ceil(maxtok / (Z2SLOTS * units)));
+                                const double rounds = std::ceil(n_ch * B * units * Z2SLOTS / slots);
+                                best_t = std::min(best_t, rounds * (fixed_us + seg * step_us));
+                            }
+                            return best_t;
+                        };
                         double cost;
-                        if (fits) cost = passes * 1.1 + steps * t_step;
+                        // LDS table: EVERY workgroup rebuilds it, one barrier-separated pass per 32 tokens of a depth
+                        // (measured round 3: ~1.9 us per pass at 10 states, ~2.8 at 20), plus launch and the in-kernel
+                        // fold (~14 us).  Round 2 priced a pass at 1.1 us and no fixed part: at 10 states and 100 x 1e6
+                        // columns it then preferred the 128-token LDS table (135 us) to the global table (102 us).
+                        if (fits) cost = 4.0 + scan_time(10.0 + passes * (1.6 + 1.2 * nt * nt * nt / 125.0), t_step);
                         else {
                             std::vector<uint64_t> cnt((size_t)A, 0);
                             for (int f : kv.second)
@@ -881,8 +904,9 @@ struct PlanBuilder {
                             const double cold_pen = table_bytes / B <= 3.6e6 ? 0.11 : 0.17;
                             const bool streamed = g.z4_stream == 1 || (g.z4_stream < 0 && table_bytes <= Z4_STREAM_MAX_BYTES);
                             // (table: one ~4.5 us launch per depth, or one ~5.7 us launch per pair of depths)
-                            const double t_table = g.table_pairs ? std::ceil(depths / 2.0) * 5.7 : depths * 4.5;
-                            cost = t_table + 8.0 + steps * t_step * (streamed ? 1.06 : 1.0 + cold_pen * cold);
+                            // (measured round 3: the first launch - it fetches the parameters - ~13 us, the others ~7.5)
+                            const double t_table = g.table_pairs ? 13.0 + (std::ceil(depths / 2.0) - 1.0) * 7.5 : 6.0 + depths * 4.9;
+                            cost = t_table + scan_time(8.0, t_step * (streamed ? 1.06 : 1.0 + cold_pen * cold));
                         }
                         if (g.blocked_variant == 5 && !fits) cost *= 1e-3;      // tests: the hybrid table wherever it is possible
                         if (cost < best) { best = cost; best_l = l; }
@@ -1005,11 +1029,17 @@ struct PlanBuilder {
                 if (kc->zip2 && g.kernel_pref != 1 && (kc->blocked_lds(gr.A) <= LDS_BUDGET || gr.zip4) && (gr.zip || (S == gr.A && S <= imc::kByteAlphabet))) {
                     size_t total = 0;
                     for (size_t L : lens) total += L;
-                    const double rows = (double)g.cus * Z2WAVES * 4;
+                    // Up to 12 states the global-table kernel needs 124 registers and no LDS to speak of: TWO workgroups share a
+                    // CU (four wavefronts per SIMD), i.e. the machine has twice the rows, each step taking ~1.85x as long
+                    // (measured at 10 states, 100 x 1e6 columns: 500 workgroups of 44-token segments 102 us, 200 workgroups
+                    // of 104-token segments 113 us).
+                    const bool two_per_cu = gr.zip4 && kc->use3() && kc->NP <= 12 &&
+                                            (double)B * (gr.A + 1) * kc->tok_doubles * 8.0 <= Z4_STREAM_MAX_BYTES;
+                    const double rows = (double)g.cus * Z2WAVES * 4 * (two_per_cu ? 2.0 : 1.0);
                     const double rb = kc->NP / 4.0;
                     // per wavefront-step (4 segments): DPP/VALU form measured ~2900 at N=20; the MFMA form issues
                     // (NP/4)^3 v_mfma_f64_4x4x4 at ~25.5 cycles each with two wavefronts per SIMD and nothing else
-                    const double step_cycles = kc->use3() ? 25.5 * rb * rb * rb * 0.55 : 5.8 * rb * rb * kc->NP;
+                    const double step_cycles = (kc->use3() ? 25.5 * rb * rb * rb * 0.55 : 5.8 * rb * rb * kc->NP) * (two_per_cu ? 1.85 : 1.0);
                     size_t seg_blk = 16;
                     double slots = 0.0, cost_blk = 1e300;
                     // a workgroup takes 32 consecutive segments of ONE chunk: rows are allocated per chunk in 32s
