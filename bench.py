@@ -454,9 +454,9 @@ def proposals(d, key, n_states, batch, T_check=None):
 
 def lookup_traffic(kernel_name, n_states, local_cols, batch):
     """HBM bytes per launch from committed PMC passes (rocprofv3 cannot run inside the bench): the measurement for this
-    kernel / N / column count if there is one (profiles/r02_traffic_pmc.json, else round 1's), else None."""
+    kernel / N / column count if there is one (profiles/r03_traffic_pmc.json, else an earlier round's), else None."""
     k = "%s|%d|%d" % (kernel_name, n_states, local_cols) + ("|B%d" % batch if batch > 1 else "")
-    for name in ("r02_traffic_pmc.json", "r01_traffic_pmc.json"):
+    for name in ("r03_traffic_pmc.json", "r02_traffic_pmc.json", "r01_traffic_pmc.json"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as fh:
                 rec = json.load(fh).get(k)
