@@ -40,7 +40,12 @@
  *   A/B switches for measurements (the default is the faster setting): IMC_TABLE_PAIRS=0 (k_zpropagate4's table one
  *   dictionary depth per launch instead of two), IMC_PACK_TABLE=0 (the mat-vec chain reads the 16-padded operator
  *   table), IMC_Z4_STREAM / IMC_BLOCKED / IMC_RANK1 (see the setters below), IMC_DICT_MIN_COUNT=n and
- *   IMC_DICT_MAX_DEPTH=d (dictionary training: occurrences a pair needs; cap on a token's depth)
+ *   IMC_DICT_MAX_DEPTH=d (dictionary training: occurrences a pair needs; cap on a token's depth),
+ *   IMC_FUSE_HEAD=0 (the parameters fetched by a k_stage_params launch and the raw operators built by k_z4_raw, instead
+ *   of by the evaluation's first table launch / by each workgroup of a small launch), IMC_TABLE_TRIPLES=1 (three
+ *   dictionary depths per table launch, one wavefront per token: measured no faster), IMC_FUSE_TAIL=0|1|2 (the chunk's
+ *   last workgroup finishes the chunk instead of stitch launches: never / chunks of at most four workgroups (default) /
+ *   wherever a chunk is at most 32 workgroups; 2 changes results by re-association only)
  *
  * fork(): a child forked AFTER the parent's first imc_* call gets IMC_ERR_HIP from every call (HIP state does not
  * survive fork and nothing of the parent's is touched); fork chain processes first, or use the spawn start method.
