@@ -34,6 +34,7 @@
 #include <set>
 #include <memory>
 #include <mutex>
+#include <condition_variable>
 #include <string>
 #include <vector>
 
@@ -54,6 +55,7 @@ namespace {
 
 thread_local std::string g_err;
 std::mutex g_mu;
+std::condition_variable g_cv;   // signalled when a plan stops being busy (see Plan::busy)
 
 int fail(int code, const std::string &msg)
 {
@@ -695,6 +697,11 @@ struct Plan {
     hipStream_t last_stream = nullptr;
     int last_slot = 0;
     bool have_last = false;
+    // A synchronous call (run_batch) enqueues under g_mu, then waits for its results WITHOUT it, so that other threads can
+    // enqueue their own evaluations behind it (round 2 held the one mutex across the wait: two Python threads with
+    // distinct chunk sets serialised completely).  While it waits the plan is `busy`: a second synchronous call on the
+    // SAME plan (they share the mapped result slots) waits on g_cv, and nothing releases a busy plan.
+    bool busy = false;
     hipGraphExec_t graph = nullptr;                 // captured enqueue(), replayed by run_batch
     uint64_t calls = 0;
     uint64_t lp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -713,6 +720,16 @@ struct Plan {
 
 std::list<std::unique_ptr<Plan>> g_plans;   // most recent first
 constexpr size_t MAX_PLANS = 4;
+
+// Wait (g_mu held through `lk`) until no synchronous call is waiting on any plan: callers that release plans.
+void wait_all_idle(std::unique_lock<std::mutex> &lk)
+{
+    g_cv.wait(lk, [] {
+        for (auto &p : g_plans)
+            if (p->busy) return false;
+        return true;
+    });
+}
 
 void drop_plans()
 {
@@ -1261,7 +1278,14 @@ struct PlanBuilder {
 
     int upload(Plan **out)
     {
-        while (g_plans.size() >= MAX_PLANS) { g_plans.back()->release(); g_plans.pop_back(); }
+        while (g_plans.size() >= MAX_PLANS) {            // least recently used first; a plan somebody waits on stays
+            auto victim = g_plans.end();
+            for (auto it = g_plans.begin(); it != g_plans.end(); ++it)
+                if (!(*it)->busy) victim = it;
+            if (victim == g_plans.end()) break;
+            (*victim)->release();
+            g_plans.erase(victim);
+        }
 
         Plan *q = p.get();
         auto up = [&](void **d, const void *h, size_t bytes) -> hipError_t {
@@ -1927,7 +1951,7 @@ hipError_t wait_results(hipStream_t st, const double *h_out, size_t n)
 int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, const double *pis, const double *Ts,
               const double *Es, double *out_sum, double *out_per_chunk)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_lock<std::mutex> lk(g_mu);
     static const bool dbg_host = std::getenv("IMC_DEBUG_HOST") != nullptr;     // diagnostics: host time per phase
     auto now = [] { return std::chrono::steady_clock::now(); };
     const auto h0 = now();
@@ -1935,7 +1959,16 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
     if (int rc = check_args(chunks, n_chunks, B, N, S, pis, Ts, Es)) return rc;
     HIP_TRY(hipSetDevice(g.device));
     Plan *p = nullptr;
-    if (int rc = build_plan(chunks, n_chunks, N, S, B, false, &p)) return rc;
+    for (;;) {                                   // (the plan is looked up again after every wait: it may have been released)
+        if (int rc = build_plan(chunks, n_chunks, N, S, B, false, &p)) return rc;
+        if (!p->busy) break;
+        g_cv.wait(lk);                           // another thread is waiting for this plan's results
+    }
+    struct Busy {                                // destroyed with g_mu held (declared after lk)
+        Plan *p;
+        explicit Busy(Plan *q) : p(q) { p->busy = true; }
+        ~Busy() { p->busy = false; g_cv.notify_all(); }
+    } busy(p);
     const auto h1 = now();
     if (int rc = stage_params(p, pis, Ts, Es, g.use_graphs)) return rc;
     const size_t n_out = (size_t)B * n_chunks;
@@ -1962,8 +1995,11 @@ int run_batch(const imc_obs *const *chunks, int n_chunks, int B, int N, int S, c
     for (int k = 0; k < 8; ++k) g.last_plan[k] = p->lp[k];
     g.last_kernels = p->kernels;
     const auto h3 = now();
-    if (!n_out) HIP_TRY(hipStreamSynchronize(g.stream));
-    else HIP_TRY(wait_results(g.stream, p->h_out, n_out));
+    const hipStream_t st = g.stream;
+    lk.unlock();                                 // other threads may enqueue their evaluations while this one waits
+    const hipError_t ew = n_out ? wait_results(st, p->h_out, n_out) : hipStreamSynchronize(st);
+    lk.lock();
+    HIP_TRY(ew);
     const auto h4 = now();
     collect_rank1_stats(p);
     if (dbg_host) {
@@ -2049,8 +2085,9 @@ int imc_device_count(void)
 
 int imc_set_device(int device)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_lock<std::mutex> lk(g_mu);
     if (device < 0) return fail(IMC_ERR_ARG, "negative device index");
+    wait_all_idle(lk);
     if (g.ready && g.pid == getpid() && g.device != device) {
         drop_plans();
         g.dicts.clear();
@@ -2260,7 +2297,8 @@ int imc_obs_recompress(imc_obs *const *chunks, int n_chunks)
                 else imc::encode_levels(nd->dict, raw[k].data(), nullptr, obs[k]->L, enc[k]);
                 std::vector<uint8_t>().swap(raw[k]);
             }
-        std::lock_guard<std::mutex> lk(g_mu);
+        std::unique_lock<std::mutex> lk(g_mu);
+        wait_all_idle(lk);
         HIP_TRY(hipSetDevice(g.device));
         HIP_TRY(hipDeviceSynchronize());                 // nothing of these chunks is in flight any more
         for (auto it = g_plans.begin(); it != g_plans.end();) {      // plans hold raw pointers into the old streams
@@ -2283,7 +2321,8 @@ int imc_obs_recompress(imc_obs *const *chunks, int n_chunks)
 int imc_obs_free(imc_obs *obs)
 {
     if (!obs) return IMC_OK;
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_lock<std::mutex> lk(g_mu);
+    wait_all_idle(lk);
     if (obs->pid == getpid() && g.ready) {
         // plans hold raw pointers into this chunk's device buffers
         for (auto it = g_plans.begin(); it != g_plans.end();) {
@@ -2413,7 +2452,8 @@ const char *imc_last_kernels(void)
 
 int imc_set_rank1_handoff(int on)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::unique_lock<std::mutex> lk(g_mu);
+    wait_all_idle(lk);
     if (g.rank1_handoff != (on != 0)) drop_plans();   // cached plans were built for the other setting
     g.rank1_handoff = on != 0;
     return IMC_OK;

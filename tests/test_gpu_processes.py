@@ -97,8 +97,9 @@ def test_fork_after_initialisation_is_refused(tmp_path):
 
 
 def test_concurrent_calls_from_threads(oracle, hmm_params, example_pairs):
-    """The Python shim releases the GIL inside the C call; the library serialises calls with one mutex.  Four
-    threads hammering different Forwarders / models must each get their own correct value."""
+    """The Python shim releases the GIL inside the C call; the library serialises the ENQUEUE of calls with one mutex (and
+    two callers of the same plan altogether).  Four threads hammering different Forwarders / models must each get their
+    own correct value."""
     from concurrent.futures import ThreadPoolExecutor
     from imcoalhmm_amd import Forwarder
     jobs = []
@@ -115,6 +116,62 @@ def test_concurrent_calls_from_threads(oracle, hmm_params, example_pairs):
     with ThreadPoolExecutor(max_workers=4) as ex:
         res = list(ex.map(work, range(8)))
     assert all(err < 1e-11 and distinct == 1 for err, distinct in res), res
+
+
+def test_threads_enqueue_while_another_waits(oracle, hmm_params):
+    """A synchronous call holds the library's mutex while it enqueues, not while it waits for its results: threads with
+    their own Forwarders must be able to queue their evaluations behind one another (round 2 serialised them completely,
+    host turn-around included).  Checked: every value is right and bit-identical call to call; a thread that shares a
+    Forwarder - and therefore a plan and its result slots - with another still gets its own values; chunks are freed
+    while other threads evaluate; and four threads together are not slower than one thread doing all the calls."""
+    import threading
+    import time
+    from imcoalhmm_amd import Forwarder, synth
+    pi, T, E = hmm_params("iso20_t0")
+    hm2 = hmm_params("iso20_t1")
+    chunks = [synth.sample_alignment(pi, T, E, 1_500_000 + 100_000 * k, seed=400 + k) for k in range(4)]
+    fws = [Forwarder.from_array(c, 3) for c in chunks]
+    want = [(oracle.forward_scaled(pi, T, E, c), oracle.forward_scaled(*hm2, c)) for c in chunks]
+    reps = 150
+
+    def work(k, out):
+        vals = []
+        for r in range(reps):
+            vals.append((fws[k].forward(pi, T, E), fws[k].forward(*hm2)))
+            if r % 50 == 7:                       # create / evaluate / free a small chunk in the middle of it all
+                g = Forwarder.from_array(chunks[k][:30_000], 3)
+                vals.append((g.forward(pi, T, E), None))
+                del g
+                vals.pop()
+        out[k] = vals
+
+    for k in range(4):
+        work(k, {})                               # plans built, caches warm
+    t0 = time.perf_counter()
+    seq = {}
+    for k in range(4):
+        work(k, seq)
+    t_seq = time.perf_counter() - t0
+    par = {}
+    threads = [threading.Thread(target=work, args=(k, par)) for k in range(4)] + [threading.Thread(target=work, args=(0, {}))]
+    t0 = time.perf_counter()
+    for th in threads[:4]:
+        th.start()
+    for th in threads[:4]:
+        th.join()
+    t_par = time.perf_counter() - t0
+    shared = {}
+    pair = [threading.Thread(target=work, args=(0, shared)), threading.Thread(target=lambda: work(0, {}))]   # two threads, ONE plan
+    for th in pair:
+        th.start()
+    for th in pair:
+        th.join()
+    for res in (seq, par, shared):
+        for k, vals in res.items():
+            assert len(set(vals)) == 1, (k, len(set(vals)))
+            assert abs(vals[0][0] - want[k][0]) <= 1e-11 * abs(want[k][0]) and abs(vals[0][1] - want[k][1]) <= 1e-11 * abs(want[k][1])
+    print("threads: sequential %.1f ms, four threads %.1f ms" % (t_seq * 1e3, t_par * 1e3))
+    assert t_par < 1.10 * t_seq, (t_seq, t_par)
 
 
 def test_integration_md_stub_is_valid(tmp_path, oracle, hmm_params, example_pairs):
