@@ -656,7 +656,14 @@ def cpu_baseline(pi, T, E, obs, cols_per_thread):
     t_plain = timed(lambda: oracle_lib.forward_chunks_mt(pi, T, E, slices, threads=cores), 4.0)
     total = float(n * cores)
     best = min(t_zip, t_plain)
+    # ... and the SAME computation as the GPU's: the whole alignment as one chain, one core (the like-for-like figure)
+    whole = obs if not cols_per_thread else obs[:cols_per_thread * cores]
+    zw = oracle_lib.Zip(whole, 3)
+    t_one = timed(lambda: oracle_lib.forward_chunks_mt(pi, T, E, [whole], threads=1, zips=[zw]), 3.0)
     return {"value": total / best, "unit": "columns/s", "cores": cores, "kind": "port",
+            "single_chain": {"value": float(whole.size) / t_one, "unit": "columns/s", "cores": 1,
+                             "sample": "the whole %d-column alignment as ONE chain on one core (what the GPU computes), "
+                                       "zipHMM-style compressed forward, compression ratio %.1fx" % (whole.size, whole.size / max(zw.length, 1))},
             "sample": "%d threads x %d columns of the same synthetic alignment (%.0f%% of it), each slice its own chunk "
                       "(so NOT the same computation as the GPU's single chain - a stated baseline, not a like-for-like "
                       "ratio), repeated for ~10 s; zipHMM-style compressed forward %.3g col/s (compression ratio %.1fx), "
