@@ -370,7 +370,7 @@ def main():
                 "kernel": kernel_name, "kernel_ms": k_ms, "operator_stream": operator_stream, "stitch_ms": s_ms,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms_covers": ("the scan launch alone (HIP events around it; its operator table is built by the "
-                                     "k_z4_raw / k_z4_level launches in front of it - durations in profiles/)"
+                                     "k_z4_level2 launches in front of it - durations in profiles/)"
                                      if "k_zpropagate4" in kernel_name else "the propagate launch(es) of one evaluation"),
                 "note": "north_star names the HBM roof, but with 1 B/column the path is bound by the fp64 units "
                         "(v_fma_f64 and v_mfma_f64 share them); see fp64",
