@@ -140,8 +140,10 @@ struct Ctx {
     int z4_stream = -1;       // k_zpropagate4's table: -1 = streamed (nothing cached in LDS) while the launch's tables are
                               // cache resident, 0 = always the hybrid LDS cache, 1 = always streamed (IMC_Z4_STREAM)
     bool table_pairs = true;  // IMC_TABLE_PAIRS=0: k_zpropagate4's table one dictionary depth per launch (A/B measurements)
-    bool table_triples = false; // IMC_TABLE_TRIPLES=1: three depths per launch, one wavefront per token (k_z4_level3) - measured no
-                               // faster than pairs (54 vs 52.5 us at 4096 tokens: 2197 wavefronts in the depth 7-9 launch), kept for A/B
+    int table_triples = -1;   // three dictionary depths per table launch, one wavefront per token (k_z4_level3): -1 = up to 12 states
+                              // (measured at 10 states: 106 vs 108 us and 113.5 vs 116 us per evaluation; at 20 states 54 vs 52.5 us for
+                              // the table - 2197 wavefronts of 125 MFMAs in the depth 7-9 launch - so pairs stay), 0 = never, 1 = always
+                              // (IMC_TABLE_TRIPLES)
     int fuse_tail = 1;        // the chunk's last workgroup finishes the chunk (zip3_tail) instead of k_chain launches: 1 = where a chunk is
                               // at most four workgroups (one in-wavefront fold; measured: 100 x 1e6 columns -1.5 us, and +6 us at 13
                               // workgroups of 20 states, where the chain's twenty parallel wavefronts win), 2 = wherever possible, 0 = never (IMC_FUSE_TAIL)
@@ -194,7 +196,7 @@ int ensure_ctx()
     if (const char *pt = std::getenv("IMC_PACK_TABLE")) g.pack_table = std::atoi(pt) != 0;
     if (const char *tp = std::getenv("IMC_TABLE_PAIRS")) g.table_pairs = std::atoi(tp) != 0;
     if (const char *fh = std::getenv("IMC_FUSE_HEAD")) g.fuse_head = std::atoi(fh) != 0;
-    if (const char *tt = std::getenv("IMC_TABLE_TRIPLES")) g.table_triples = std::atoi(tt) != 0;
+    if (const char *tt = std::getenv("IMC_TABLE_TRIPLES")) g.table_triples = std::atoi(tt) != 0 ? 1 : 0;
     if (const char *ft = std::getenv("IMC_FUSE_TAIL")) g.fuse_tail = std::max(0, std::min(2, std::atoi(ft)));
     if (const char *zs = std::getenv("IMC_Z4_STREAM")) { const int v = std::atoi(zs); if (v >= -1 && v <= 1) g.z4_stream = v; }
     g.pid = me;
@@ -1765,7 +1767,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out, bool allow_tail = true)
                     hipLaunchKernelGGL(kc->zip4_raw, dim3((unsigned)S + 1, (unsigned)B), dim3(256), 0, stream, ba);
                     HIP_TRY(hipGetLastError());
                 }
-                if (g.table_pairs && g.table_triples && gr.d_tab_desc3) {
+                if (g.table_pairs && (g.table_triples == 1 || (g.table_triples < 0 && NP <= 12)) && gr.d_tab_desc3) {
                     bool head = fuse_head;
                     if (!kc->zip4_attr_l3) {
                         HIP_TRY(hipFuncSetAttribute((const void *)kc->zip4_level3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));

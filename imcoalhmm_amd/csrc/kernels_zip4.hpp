@@ -413,9 +413,11 @@ struct Z4Tok {              // one step's operator for this lane's segment (kept
 // Pout <- C_cur * Pin.  `al` holds tile-row 0 of cur's LDS entry on entry and of nxt's on exit (as zip3_step);
 // `pre` holds ALL tile-rows of cur's global entry if cur is cold, and is refilled tile-row by tile-row with nxt's
 // entry (if that is cold) as soon as each row has been consumed.
+// `refill`: the token whose global entry goes into `pre` behind the rows just consumed - the next step's (one register
+// set) or the one after (two sets: see Zip4Ring).
 template <int NT, bool HYB>
 __device__ __forceinline__ void zip4_step(const double (&Pin)[NT][NT], double (&Pout)[NT][NT], const double *C, const double *Gt, const double *Gi,
-                                          const Z4Tok &cur, const Z4Tok &nxt, double (&al)[NT], double (&pre)[NT][NT], int lo, int lx)
+                                          const Z4Tok &cur, const Z4Tok &nxt, const Z4Tok &refill, double (&al)[NT], double (&pre)[NT][NT], int lo, int lx)
 {
     constexpr int TOK = Zip3Geom<NT>::TOK;
     // The refill is issued for EVERY step - a hot next token fetches the identity entry `Gi` instead (the same few
@@ -424,8 +426,8 @@ __device__ __forceinline__ void zip4_step(const double (&Pin)[NT][NT], double (&
     // them, vmcnt(0), at the top of every step: the L2 round trip of the last tile-row, issued 25 MFMAs earlier, was
     // exposed on every cold step).
     // HYB = false (streamed table): no LDS copies at all - every operand comes from `pre`.
-    const bool cur_cold = !HYB || cur.s < 0, nxt_cold = !HYB || nxt.s < 0;
-    const double *Gn = nxt_cold ? Gt + (size_t)nxt.tok * TOK : Gi;
+    const bool cur_cold = !HYB || cur.s < 0, nxt_cold = !HYB || refill.s < 0;
+    const double *Gn = nxt_cold ? Gt + (size_t)refill.tok * TOK : Gi;
     // (a cold token reads LDS slot 0: a valid address whose data is not used)
     const double *Cz = C + (size_t)max(cur.s, 0) * TOK, *Cn = C + (size_t)max(nxt.s, 0) * TOK;
 #pragma unroll
@@ -541,11 +543,19 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     const int maxlen = wave_max_i32(len);
     const int nfull = maxlen == 0 ? 0 : wave_min_i32(valid ? len / RESCALE_EVERY : INT_MAX);   // idle wavefronts still join the fold's barriers
 
-    double al[NT] = {}, pre[NT][NT];
+    // Register sets of global-table operands.  One set, refilled with the NEXT step's operator, hides an L2 round trip
+    // behind a step of 125 MFMAs (20 states); at 16 states and below a step (<= 64 MFMAs, <= 0.5 us) is shorter than that
+    // round trip and the streamed form keeps TWO sets, each refilled with the operator two steps ahead (microbenchmark
+    // profiles/tools/micro/mb_scan_ring3.hip, 10 states: 60.0 -> 35.4 us for the planner's 100 x 1e6-column shape, the
+    // MFMA instruction's own rate; at 20 states the same change is slower: mb_scan_ring2.hip).
+    constexpr int RING = (!HYB && NT <= 4) ? 2 : 1;
+    double al[NT] = {}, pre[RING][NT][NT];
 #pragma unroll
-    for (int I = 0; I < NT; ++I)
+    for (int d = 0; d < RING; ++d)
 #pragma unroll
-        for (int K = 0; K < NT; ++K) pre[I][K] = 0.0;
+        for (int I = 0; I < NT; ++I)
+#pragma unroll
+            for (int K = 0; K < NT; ++K) pre[d][I][K] = 0.0;
     auto mk = [&](int tok) __attribute__((always_inline)) {
         Z4Tok t;
         t.s = HYB ? slot_of[tok] : -1;
@@ -555,15 +565,27 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     };
     // start (or restart) the pipeline at `c`: its LDS row 0 and, if it is cold, all of its global rows - exposed latency,
     // paid at the start of a segment and where the token of the next position is not known a step ahead
-    auto prime = [&](const Z4Tok &c) __attribute__((always_inline)) {
+    // (c1: the token of the position after c - only the two-set form loads it)
+    auto prime = [&](const Z4Tok &c, const Z4Tok &c1) __attribute__((always_inline)) {
         if constexpr (HYB) zip3_load_row<NT>(al, C + (size_t)max(c.s, 0) * TOK, 0, lo, lx);
         const double *Gc0 = c.s < 0 ? Gt + (size_t)c.tok * TOK : Gi;        // (unconditional, as zip4_step's refill)
 #pragma unroll
-        for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(pre[I], Gc0, I, lo, lx);
+        for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(pre[0][I], Gc0, I, lo, lx);
+        if constexpr (RING == 2) {
+            const double *Gc1 = Gt + (size_t)c1.tok * TOK;
+#pragma unroll
+            for (int I = 0; I < NT; ++I) zip4_load_row_global<NT>(pre[1][I], Gc1, I, lo, lx);
+        }
     };
-    auto two_steps = [&](const Z4Tok &t0, const Z4Tok &t1, const Z4Tok &tn) __attribute__((always_inline)) {
-        zip4_step<NT, HYB>(P, Q, C, Gt, Gi, t0, t1, al, pre, lo, lx);
-        zip4_step<NT, HYB>(Q, P, C, Gt, Gi, t1, tn, al, pre, lo, lx);
+    // two steps on t0, t1; tn, tn1: the tokens of the two positions behind them (tn1 only matters to the two-set form)
+    auto two_steps = [&](const Z4Tok &t0, const Z4Tok &t1, const Z4Tok &tn, const Z4Tok &tn1) __attribute__((always_inline)) {
+        if constexpr (RING == 2) {
+            zip4_step<NT, HYB>(P, Q, C, Gt, Gi, t0, t1, tn, al, pre[0], lo, lx);
+            zip4_step<NT, HYB>(Q, P, C, Gt, Gi, t1, tn, tn1, al, pre[1], lo, lx);
+        } else {
+            zip4_step<NT, HYB>(P, Q, C, Gt, Gi, t0, t1, t1, al, pre[0], lo, lx);
+            zip4_step<NT, HYB>(Q, P, C, Gt, Gi, t1, tn, tn, al, pre[0], lo, lx);
+        }
         ex += t0.ce + t1.ce;
     };
     // A block of 16 positions in which not every lane's segment has a token (see k_zpropagate3): per run of PER positions
@@ -584,13 +606,14 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
             const int tk = WIDE ? (int)((h >> (16 * (v & 3))) & 0xffffull) : (int)((h >> (8 * (v & 7))) & 0xffull);
             return (v < live && v != dead0 && v < PER) ? tk : IDENT;
         };
-        Z4Tok c0 = mk(tok_of(0));
-        prime(c0);
+        Z4Tok c0 = mk(tok_of(0)), c1 = mk(tok_of(1));
+        prime(c0, c1);
 #pragma unroll 1
         for (int v = 0; v < n; v += 2) {
-            const Z4Tok c1 = mk(tok_of(v + 1)), c2 = mk(tok_of(v + 2));
-            two_steps(c0, c1, c2);
+            const Z4Tok c2 = mk(tok_of(v + 2)), c3 = mk(tok_of(v + 3));
+            two_steps(c0, c1, c2, c3);
             c0 = c2;
+            c1 = c3;
         }
     };
     auto masked_block = [&](int bi, int npos) __attribute__((always_inline)) {
@@ -620,7 +643,7 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
         uint32_t cw[NW];
         load_words(0, cw);
         Z4Tok c0 = mk(first ? IDENT : (int)(cw[0] & TM));
-        prime(c0);
+        prime(c0, mk(WIDE ? (int)(cw[0] >> 16) : (int)((cw[0] >> 8) & TM)));
         for (int bi = 0; bi < nfull; ++bi) {
             // Straight-line body (no load under a branch: the compiler then waits for exactly the loads it needs): the
             // next block's first token now (one word), its other words once this block's have been consumed; behind
@@ -644,11 +667,14 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
                     t1 = (int)((wa >> 8) & TM); t2 = (int)((wa >> 16) & TM); t3 = (int)(wa >> 24);
                 }
                 t4 = g4 < 3 ? (int)(cw[0] & TM) : more ? (int)(nfirst & TM) : IDENT;
+                // (the token behind t4: only the two-set form looks two steps ahead)
+                const uint32_t w5 = g4 < 3 ? cw[0] : nfirst;
+                const int t5 = (g4 < 3 || more) ? (WIDE ? (int)(w5 >> 16) : (int)((w5 >> 8) & TM)) : IDENT;
                 if (g4 == 3) load_words(bn, cw);                          // lands during the last four steps of this block
-                const Z4Tok c1 = mk(t1), c2 = mk(t2);
-                two_steps(c0, c1, c2);
-                const Z4Tok c3 = mk(t3), c4 = mk(t4);
-                two_steps(c2, c3, c4);
+                const Z4Tok c1 = mk(t1), c2 = mk(t2), c3 = mk(t3);
+                two_steps(c0, c1, c2, c3);
+                const Z4Tok c4 = mk(t4), c5 = mk(t5);
+                two_steps(c2, c3, c4, c5);
                 c0 = c4;
             }
             zip3_rescale<NT>(P, ex);

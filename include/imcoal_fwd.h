@@ -42,8 +42,8 @@
  *   table), IMC_Z4_STREAM / IMC_BLOCKED / IMC_RANK1 (see the setters below), IMC_DICT_MIN_COUNT=n and
  *   IMC_DICT_MAX_DEPTH=d (dictionary training: occurrences a pair needs; cap on a token's depth),
  *   IMC_FUSE_HEAD=0 (the parameters fetched by a k_stage_params launch and the raw operators built by k_z4_raw, instead
- *   of by the evaluation's first table launch / by each workgroup of a small launch), IMC_TABLE_TRIPLES=1 (three
- *   dictionary depths per table launch, one wavefront per token: measured no faster), IMC_FUSE_TAIL=0|1|2 (the chunk's
+ *   of by the evaluation's first table launch / by each workgroup of a small launch), IMC_TABLE_TRIPLES=0|1 (three
+ *   dictionary depths per table launch, one wavefront per token: never / always; default: up to 12 states, where it is 2 % faster), IMC_FUSE_TAIL=0|1|2 (the chunk's
  *   last workgroup finishes the chunk instead of stitch launches: never / chunks of at most four workgroups (default) /
  *   wherever a chunk is at most 32 workgroups; 2 changes results by re-association only)
  *
