@@ -26,8 +26,11 @@
  *
  * Threads / processes: no HIP call is made before the first compute/create call, and the device
  * context is re-created lazily per PID, so Forwarders may be built inside multiprocessing
- * children as mcmc.py:112-121 does.  HIP calls are serialised internally by one mutex; the O(L) host work of
- * imc_obs_create* (validation, dictionary training, encoding) runs outside it.
+ * children as mcmc.py:112-121 does.  One mutex serialises the ENQUEUE of calls (plan lookup, parameter staging, kernel
+ * launches); a synchronous call waits for its results without it, so other threads queue their evaluations behind it
+ * (two synchronous calls on the SAME chunk list share a plan's result slots and run one after the other; a chunk is not
+ * freed, and no plan released, while somebody waits on it).  The O(L) host work of imc_obs_create* (validation,
+ * dictionary training, encoding) runs outside the mutex.
  *
  * Environment (diagnostics only, read when a plan is built / the context is created):
  *   IMC_DEBUG=1        print the planner's cost estimates to stderr
