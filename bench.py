@@ -70,6 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling of BASELINE config[3]: --chunks (default 256) chunks of --columns (default 1e7) "
                          "columns in TOTAL, dealt round-robin over the ranks; with --gpus 1 all of them on one GPU")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="--gpus 1 only: run the step through the N-rank code path - a world-size-1 nccl (RCCL) group, the "
+                         "device-output entry point on torch's stream and the all_reduce - to price that path on one GPU")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses device 0 and the reduction runs "
                          "over gloo (RCCL refuses two ranks on one device); never used for reported numbers")
@@ -219,7 +222,7 @@ def main():
     # ---- synthetic data: everything this process will need, generated before the GPU is touched ----
     t0 = time.time()
     requests = [("main%d" % i, key, cols, sd) for i, sd in enumerate(seeds)]
-    extras = world == 1 and not args.no_extra and args.batch == 1 and not args.fixture and workload_kind == "config2" \
+    extras = world == 1 and not args.no_extra and not args.force_collective and args.batch == 1 and not args.fixture and workload_kind == "config2" \
         and not args.no_compress and args.mode < 0 and n_states == 20 and not args.columns and not args.chunks
     if extras:
         requests += [("c3", "im150_t0", 100_000_000, 20240002)]
@@ -242,6 +245,12 @@ def main():
     _capi.check(lib.imc_set_device(dev_index))
     _capi.check(lib.imc_set_compression(args.mode if args.mode >= 0 else (0 if args.no_compress else 1)))
     backend = None
+    if world == 1 and args.force_collective:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        backend = "nccl (world size 1, --force-collective)"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = "gloo" if args.rehearse_on_one_gpu else "nccl"
@@ -273,7 +282,8 @@ def main():
     if split:
         ll = SplitAlignmentLikelihood(FixedModel(), forwarders[0], gather_device=None if args.rehearse_on_one_gpu else dev)
     else:
-        ll = DistributedLikelihood(FixedModel(), forwarders, device=dev, reduce_on_host=args.rehearse_on_one_gpu)
+        ll = DistributedLikelihood(FixedModel(), forwarders, device=dev, reduce_on_host=args.rehearse_on_one_gpu,
+                                   force_collective=args.force_collective)
 
     model_build_ms = None
     if args.batch > 1:
@@ -394,7 +404,7 @@ def main():
             out["extra_configs"] = ex
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.barrier()
         dist.destroy_process_group()
 
