@@ -17,7 +17,7 @@ __device__ __forceinline__ void grow(double (&a)[NT], const double *Gz, int I, i
     a[0] = v0.x; a[1] = v0.y; a[2] = v1.x; a[3] = v1.y;
     a[4] = Gz[320 + I * 16 + lx];
 }
-template <int DEPTH, int WAVES>
+template <int DEPTH, int WAVES, bool TOUCH = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(const double *table, int steps, const int *toks, double *out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,8 +47,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(const double *table, 
             grow(A[I], Gn, I, lo, lx);
         }
     };
+    // TOUCH: an L2 warm-up of the operator TWO steps ahead - one 8-byte load per lane and 128-byte line (lane lx of the
+    // segment's 16 takes lines lx and 16 + lx of the entry's 25), issued at the top of a step and only waited for two steps
+    // later (the values are thrown away) - in front of the one-step register refill
+    double tch[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    auto touch = [&](int tok, double (&t)[2]) __attribute__((always_inline)) {
+        const double *G = table + (size_t)tok * TOK;
+        t[0] = G[lx * 16];
+        t[1] = G[(lx < 9 ? 16 + lx : 24) * 16];
+    };
+    auto sink = [&](double (&t)[2]) __attribute__((always_inline)) { asm volatile("" ::"v"(t[0]), "v"(t[1])); };
     for (int s = 0; s < steps; s += 2) {
-        if constexpr (DEPTH == 1) {
+        if constexpr (DEPTH == 1 && TOUCH) {
+            sink(tch[0]); touch(tp[s + 2], tch[0]);
+            step(P, Q, pre[0], tp[s + 1]);
+            sink(tch[1]); touch(tp[s + 3], tch[1]);
+            step(Q, P, pre[0], tp[s + 2]);
+        } else if constexpr (DEPTH == 1) {
             step(P, Q, pre[0], tp[s + 1]);
             step(Q, P, pre[0], tp[s + 2]);
         } else {
@@ -66,7 +81,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void k(const double *table, 
     for (int i = 0; i < NT; ++i) for (int j = 0; j < NT; ++j) acc += P[i][j];
     out[blockIdx.x * 512 + threadIdx.x] = acc;
 }
-template <int DEPTH, int WAVES>
+template <int DEPTH, int WAVES, bool TOUCH = false>
 int run(const char *name, const double *tab, int steps_per_slot8, const int *toks, double *out)
 {
     const int steps = steps_per_slot8 * 8 / WAVES;          // same work per CU
@@ -74,7 +89,7 @@ int run(const char *name, const double *tab, int steps_per_slot8, const int *tok
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((k<DEPTH, WAVES>), dim3(255), dim3(WAVES * 64), 0, 0, tab, steps, toks, out);
+        hipLaunchKernelGGL((k<DEPTH, WAVES, TOUCH>), dim3(255), dim3(WAVES * 64), 0, 0, tab, steps, toks, out);
         hipEventRecord(e1); CHECK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
     }
@@ -102,6 +117,7 @@ int main()
         CHECK(hipMemcpy(toks, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
         printf("tokens: %s\n", skew ? "91 % of the steps from 1024 entries (3.3 MB, L2 resident), the rest uniform over 4096" : "uniform over 4096 entries (13 MB: most steps miss the 4 MB L2)");
         if (run<1, 8>("one register set, 8 wavefronts per CU (k_zpropagate4's loop)", tab, steps8, toks, out)) return 1;
+        if (run<1, 8, true>("  + L2 warm-up touch two steps ahead", tab, steps8, toks, out)) return 1;
         if (run<1, 4>("one register set, 4 wavefronts per CU", tab, steps8, toks, out)) return 1;
         if (run<2, 4>("two register sets (two steps ahead), 4 wavefronts per CU", tab, steps8, toks, out)) return 1;
         if (run<2, 8>("two register sets, 8 wavefronts per CU (if the registers allow)", tab, steps8, toks, out)) return 1;
