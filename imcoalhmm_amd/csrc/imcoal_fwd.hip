@@ -1080,8 +1080,14 @@ struct PlanBuilder {
                         const double table = !kc->use3() ? (double)(gr.A - S) * (400.0 + (double)kc->NP * kc->NP * kc->NP / 64.0)
                                              : gr.zip4 ? 9000.0 : 2600.0 * std::min(12.0, (double)(gr.A - S));
                         const double fixed = table + 5.0 * (Z2WAVES / 4.0) * step_cycles;
-                        const double c = std::ceil(used * B / rows) * ((double)sg * (Z2WAVES / 4.0) * step_cycles + fixed);
-                        if (c < cost_blk) { cost_blk = c; seg_blk = sg; slots = used; }
+                        // A segment length that is not a multiple of 16 ends in a MASKED block (the pipeline is re-primed per
+                        // run of it: ~3.5 us; measured at 10 states, 100 x 1e6 columns: 48-token segments 101.9 us, 44-token
+                        // ones 109.6) - so the next multiple of 16 is priced beside the exact fit.
+                        for (size_t cand : {sg, round_up(sg, 16)}) {
+                            const double u = rows_used(cand);
+                            const double c = std::ceil(u * B / rows) * ((double)cand * (Z2WAVES / 4.0) * step_cycles + fixed + (cand % 16 ? 7700.0 : 0.0));
+                            if (c < cost_blk) { cost_blk = c; seg_blk = cand; slots = u; }
+                        }
                     }
                     if (std::getenv("IMC_DEBUG"))
                         std::fprintf(stderr, "[imc] plan: vector kernel seg %zu cost %.3g cycles; blocked kernel seg %zu slots %.0f cost %.3g cycles\n",
