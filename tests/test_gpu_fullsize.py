@@ -189,3 +189,54 @@ def test_config4_slice_64_proposals_32_chunks_of_1e6(hmm_params, hmm_params_file
     hf = Forwarder.from_array(head, 3)
     for b in (0, 40):
         assert rel_err(hf.forward(pis[b], Ts[b], Es[b]), oracle.forward_scaled(pis[b], Ts[b], Es[b], head)) < 1e-11
+
+
+def test_full_size_10_states_closed_form_and_invariances(big, hmm_params, oracle):
+    """The reference's default model size (--states 10, scripts/isolation-model.py:43) on the same 1e8 columns, and on the
+    authors' data shape - 100 chunks of 1e6 columns (simulations/isolation-model/simulate.sh:11): the small-N schedule of
+    round 3 (global table chosen by the planner, three dictionary depths per table launch, two operand register sets, two
+    workgroups per CU, 48-token segments) against the count-only closed form, against another segmentation, against the
+    raw per-column kernels, bit-identical repeats, and the CPU oracle on every tenth chunk."""
+    obs, f = big
+    pi, T, E = hmm_params("iso10_t0")
+    L = _capi.lib()
+    vals = [f.forward(pi, T, E) for _ in range(3)]
+    kernels = _capi.last_plan()["kernels"]
+    assert len(set(vals)) == 1 and math.isfinite(vals[0])
+    assert "k_zpropagate4<3" in kernels, kernels                   # the planner's choice at this size (not the 128-token LDS table)
+    try:
+        L.imc_set_segment_length(20_000)
+        b = f.forward(pi, T, E)
+    finally:
+        L.imc_set_segment_length(0)
+    assert rel_err(vals[0], b) < 1e-12, (vals[0], b)
+    # closed form through the same schedule: rank-one T
+    n, nsym = 10, 3
+    rng = np.random.default_rng(12)
+    q = rng.random(n); q /= q.sum()
+    E1 = rng.random((n, nsym)); E1 /= E1.sum(axis=1, keepdims=True)
+    p1 = rng.random(n); p1 /= p1.sum()
+    cnt = np.bincount(obs[1:], minlength=nsym)
+    want = math.log(p1 @ E1[:, obs[0]]) + float(cnt @ np.log(q @ E1))
+    assert rel_err(f.forward(p1, np.tile(q, (n, 1)), E1), want) < 1e-10
+    # 100 x 1e6: chunk values against the oracle (every tenth), the sum against the chunk values, and the raw kernels
+    from imcoalhmm_amd.hmm import forward_chunks, forward_chunks_batch, recompress
+    chunks = [obs[k * 1_000_000:(k + 1) * 1_000_000] for k in range(100)]
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    recompress(fw)
+    h = [x.handle for x in fw]
+    per = forward_chunks_batch(h, pi[None], T[None], E[None], per_chunk=True)[0]
+    tot = forward_chunks(h, pi, T, E)
+    s = 0.0
+    for v in per:
+        s += v
+    assert tot == s                                              # the library's left-to-right sum (likelihood.py:33)
+    assert "k_zpropagate4<3" in _capi.last_plan()["kernels"]
+    for k in range(0, 100, 10):
+        assert rel_err(per[k], oracle.forward_scaled(pi, T, E, chunks[k])) < 1e-11, k
+    try:
+        L.imc_set_compression(0)
+        raw = [Forwarder.from_array(chunks[k], 3).forward(pi, T, E) for k in (3, 57)]
+    finally:
+        L.imc_set_compression(1)
+    assert rel_err(raw[0], per[3]) < 1e-12 and rel_err(raw[1], per[57]) < 1e-12
