@@ -527,7 +527,14 @@ def extra_configs(lib, d, data, fence):
         fw, lambda: _capi.forward1(h, 100, pi10, T10, E10), 1e8, 1, 20, 5)
     res[-1]["setup_s"] = time.time() - t0
     res[-1]["us_per_evaluation"] = plain_latency_us(lambda: _capi.forward1(h, 100, pi10, T10, E10), 50)
-    del fw, h
+    # ... and a population on the same files: 64 proposals per step (PSO / GA populations are 100, MC3 rounds k chains:
+    # particle_swarm.py:97-99, genetic_algorithm.py:750-754) - chunks x proposals alone are 25 rounds of workgroups here
+    pis, Ts, Es, ms = proposals(d, "iso10_t0", 10, 64)
+    hl = [f.handle for f in fw]
+    run("isolation-model 10 states, 64 proposals/step x 100 x 1000000-column chunks (a population at the authors' data scale)",
+        fw, lambda: float(forward_chunks_batch(hl, pis, Ts, Es)[0]), 1e8, 64, 5, 2)
+    res[-1]["model_build_ms_per_hmm"] = ms
+    del fw, h, hl
     # config[2]: ~150 states (IsolationMigrationModel(75, 75)), one 1e8-column alignment
     pi, T, E = d["im150_t0_pi"], d["im150_t0_T"], d["im150_t0_E"]
     t0 = time.time()

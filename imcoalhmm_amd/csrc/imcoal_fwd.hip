@@ -1067,12 +1067,28 @@ struct PlanBuilder {
                         for (size_t L : lens) r += std::ceil(std::ceil((double)L / (double)sg) / Z2SLOTS) * Z2SLOTS;
                         return r;
                     };
-                    for (int rounds = 1; rounds <= 16; ++rounds) {               // fill the machine's rows `rounds` times
+                    // Candidates: fill the machine's rows `rounds` times - or, when chunks x parameter sets alone need more
+                    // rounds than that (every chunk takes at least one workgroup of 32 rows per parameter set: 100 chunks x 64
+                    // sets = 25 rounds), cut every chunk into u workgroups' worth of segments.  (Round 2 only had the first
+                    // family, up to 16 rounds; beyond that its search ran into its iteration limit and returned segments of
+                    // thousands of tokens with two of a workgroup's 32 rows in use: 100 x 1e6 columns x 64 proposals took
+                    // 446 us per proposal at 10 states against 64 us at 8 proposals.)
+                    size_t lmax = 0;
+                    for (size_t L : lens) lmax = std::max(lmax, L);
+                    std::vector<size_t> cands;
+                    for (int rounds = 1; rounds <= 16; ++rounds) {
                         const double target = std::max((double)Z2SLOTS, std::floor(rows * rounds / B));
                         // (the blocked kernels take segments of any multiple of 4 tokens - dword-aligned 16-byte
                         // loads - so the machine's rows can be filled to within a per cent, not to within 16 tokens)
                         size_t sg = std::max<size_t>(16, round_up((size_t)std::ceil((double)total / target), Z2GRAN));
-                        for (int it = 0; it < 1024 && rows_used(sg) > target; ++it) sg += Z2GRAN;
+                        int it = 0;
+                        for (; it < 1024 && rows_used(sg) > target && sg < lmax + 16; ++it) sg += Z2GRAN;
+                        if (rows_used(sg) > target) continue;                    // this many rounds cannot hold the launch
+                        cands.push_back(sg);
+                    }
+                    for (size_t u = 1; u <= 8; ++u)
+                        cands.push_back(std::max<size_t>(16, round_up((lmax + Z2SLOTS * u - 1) / (Z2SLOTS * u), Z2GRAN)));
+                    for (size_t sg : cands) {
                         const double used = rows_used(sg);
                         // per round of workgroups: the main loop, plus the table rebuild and the 5-level in-kernel fold
                         // (table: the VALU form builds token by token; the MFMA form one dictionary depth per pass,

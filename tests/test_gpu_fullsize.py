@@ -197,9 +197,11 @@ def test_full_size_10_states_closed_form_and_invariances(big, hmm_params, oracle
     round 3 (global table chosen by the planner, three dictionary depths per table launch, two operand register sets, two
     workgroups per CU, 48-token segments) against the count-only closed form, against another segmentation, against the
     raw per-column kernels, bit-identical repeats, and the CPU oracle on every tenth chunk."""
-    obs, f = big
+    obs, _ = big
     pi, T, E = hmm_params("iso10_t0")
     L = _capi.lib()
+    _capi.check(L.imc_dictionary_reset())        # (the process-wide dictionary may have been trained by an earlier, small test)
+    f = Forwarder.from_array(obs, 3)
     vals = [f.forward(pi, T, E) for _ in range(3)]
     kernels = _capi.last_plan()["kernels"]
     assert len(set(vals)) == 1 and math.isfinite(vals[0])
@@ -221,6 +223,7 @@ def test_full_size_10_states_closed_form_and_invariances(big, hmm_params, oracle
     assert rel_err(f.forward(p1, np.tile(q, (n, 1)), E1), want) < 1e-10
     # 100 x 1e6: chunk values against the oracle (every tenth), the sum against the chunk values, and the raw kernels
     from imcoalhmm_amd.hmm import forward_chunks, forward_chunks_batch, recompress
+    del f
     chunks = [obs[k * 1_000_000:(k + 1) * 1_000_000] for k in range(100)]
     fw = [Forwarder.from_array(c, 3) for c in chunks]
     recompress(fw)

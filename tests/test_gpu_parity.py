@@ -694,3 +694,26 @@ def test_hybrid_table_kernel(oracle, n, seg, stream):
             w = want[b][k]
             assert (got[b][k] == 0.0 and w == 0.0) or rel_err(got[b][k], w) < TOL, (n, seg, b, k, got[b][k], w)
             assert (lds[b][k] == 0.0 and w == 0.0) or rel_err(lds[b][k], w) < TOL
+
+
+def test_many_chunks_times_many_proposals_plan(oracle, hmm_params):
+    """A GA / PSO population or 64 MC3 chains over many alignment files: chunks x parameter sets alone need more rounds of
+    workgroups than the planner's search used to cover (every chunk takes at least one workgroup of 32 segment rows per
+    parameter set).  Round 2's search then ran into its iteration limit and cut each chunk into TWO segments of thousands
+    of tokens - 2 of a workgroup's 32 rows in use, 7x slower per proposal (100 x 1e6 columns, 64 proposals).  The plan
+    must cut a chunk into (a multiple of) 32 segments, and the values must be right."""
+    pi, T, E = hmm_params("iso10_t0")
+    hm = [hmm_params("iso10_t%d" % (b % 3)) for b in range(72)]
+    pis, Ts, Es = (np.stack([h[k] for h in hm]) for k in range(3))
+    chunks = [synth.sample_alignment(pi, T, E, 60_000 + 500 * k, seed=700 + k) for k in range(70)]
+    fw = [Forwarder.from_array(c, 3) for c in chunks]
+    per = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+    plan = _capi.last_plan()
+    longest = max(f.compressed_length(plan["token_alphabet"] or 256)[0] for f in fw) if plan["vector_tokens"] else max(len(c) for c in chunks)
+    seglen = plan["token_segment_len"] or plan["column_segment_len"]
+    assert seglen <= 2 * (longest // 32 + 16), (seglen, longest, plan)           # ~ longest / 32, not longest / 2
+    assert plan["segments"] >= 16 * len(chunks), plan
+    for b in (0, 1, 2, 71):
+        for k in (0, 33, 69):
+            assert rel_err(per[b][k], oracle.forward_scaled(pis[b], Ts[b], Es[b], chunks[k])) < TOL, (b, k)
+    assert np.array_equal(per[0], per[3]) and np.array_equal(per[1], per[70])       # same parameter set, same bits
