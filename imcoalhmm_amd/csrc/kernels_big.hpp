@@ -688,6 +688,7 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
     constexpr bool ROWS = NT >= BS_WAVES;
     constexpr int NTILES = NT * TCS, NEXTRA = ROWS ? (NT - BS_WAVES) * TCS : NTILES;
     constexpr int JROW = ROWS ? TCS : 0, JMAX = JROW + (NEXTRA + BS_WAVES - 1) / BS_WAVES;
+    constexpr int JMAX_ALL = JROW + NEXTRA / BS_WAVES;   // tiles every wavefront owns
     constexpr int PANEL_D2 = NP * 8, EPT = (PANEL_D2 + THREADS - 1) / THREADS;   // double2 per panel, per thread
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *slab = lds;                              // [NP][SPS]  P[k][c - c0]
@@ -773,15 +774,22 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
         const int j = ROWS ? (f == 0 ? 0 : JROW + f - 1) : f;
         fo[f] = (size_t)(a_off[j] / APS) * NP + 4 * lg;          // a_off[j] = (16 tr + lm) * APS + 4 lg
     }
-    double2 fn[NF][2];
+    // THREE register sets: panel kb is consumed from set kb % 3 while the loads of panels kb + 1 and kb + 2 are in
+    // flight (every step's operator is new to the chip - 205 KB per segment and step, 2.7 TB/s over the launch - so a
+    // fetch is an HBM round trip, longer than the 1.5 us one panel's MFMAs take; with a single set ahead every panel
+    // ended in a wait).  The k loop is unrolled over the step's NT panels so that the set of a panel is a compile-time
+    // name; between steps the two sets in flight are renamed (register moves behind the step's barriers).
+    double2 fr[3][NF][2];
 #pragma unroll
-    for (int f = 0; f < NF; ++f) fn[f][0] = fn[f][1] = double2{0.0, 0.0};
-    auto fetch = [&](const double *A, int kb) __attribute__((always_inline)) {
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) fr[d][f][0] = fr[d][f][1] = double2{0.0, 0.0};
+    auto fetch = [&](double2 (&dst)[NF][2], const double *A, int kb) __attribute__((always_inline)) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             const double2 *src = reinterpret_cast<const double2 *>(A + fo[f] + kb * 16);
-            fn[f][0] = src[0];
-            fn[f][1] = src[1];
+            dst[f][0] = src[0];
+            dst[f][1] = src[1];
         }
     };
     int tok = t_begin < t_end ? seg_token(tokp, wide, t_begin) : 0;
@@ -790,7 +798,7 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
     for (int k = 0; k < EPT; ++k) sa[k] = double2{0.0, 0.0};
     if (t_begin < t_end) {
         const double *A0 = Ct + (size_t)tok * NP * NP;
-        if constexpr (DIRECT_A) fetch(A0, 0);
+        if constexpr (DIRECT_A) { fetch(fr[0], A0, 0); fetch(fr[1], A0, 1); }
         else {
 #pragma unroll
             for (int k = 0; k < EPT; ++k)
@@ -807,30 +815,33 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
             cex_cur = cex[tok];
             const int tok_next = t + 1 < t_end ? seg_token(tokp, wide, t + 1) : tok;
             const double *An = Ct + (size_t)tok_next * NP * NP;
-#pragma unroll 2
-            for (int kb = 0; kb < NP / 16; ++kb) {
-                double2 fc[NF][2];
 #pragma unroll
-                for (int f = 0; f < NF; ++f) { fc[f][0] = fn[f][0]; fc[f][1] = fn[f][1]; }
-                if (kb + 1 < NP / 16) fetch(A, kb + 1);
-                else fetch(An, 0);                                   // the next token's first panel (last step: a harmless reload)
+            for (int kb = 0; kb < NT; ++kb) {
+                // (behind the token's last panels: the next token's first two; last step: a harmless reload)
+                if (kb + 2 < NT) fetch(fr[(kb + 2) % 3], A, kb + 2);
+                else fetch(fr[(kb + 2) % 3], An, kb + 2 - NT);
+                const double2 (&fc)[NF][2] = fr[kb % 3];
                 const double *Bk = slab + (size_t)kb * 16 * SPS;
-                if constexpr (ROWS) {   // the wavefront's own tile-row: one A fragment for TCS tiles
-                    const double av[4] = {fc[0][0].x, fc[0][0].y, fc[0][1].x, fc[0][1].y};
+                // One pass over k = 4 s2 .. 4 s2 + 3 for ALL of the wavefront's tiles: the four products of a tile are
+                // dependent (same accumulator) and stay a tile-count apart, and every B operand of the panel can be read
+                // ahead of its product (the dealt tiles used to run one after the other, each behind its own LDS read).
+                // Only the product of the LAST dealt tile is conditional (waves below NEXTRA % 8 own one more tile; its
+                // operands are valid for every wavefront - unused slots repeat tile 0).
+                double bv[4][JMAX];
 #pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2)
+                for (int s2 = 0; s2 < 4; ++s2)
 #pragma unroll
-                        for (int j = 0; j < JROW; ++j)
-                            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[b_off[0] + s2 * SPS + j * 16], acc[j], 0, 0, 0);
-                }
+                    for (int j = 0; j < JMAX; ++j)
+                        bv[s2][j] = (ROWS && j < JROW) ? Bk[b_off[0] + s2 * SPS + j * 16] : Bk[b_off[j] + s2 * SPS];
 #pragma unroll
-                for (int j = JROW; j < JMAX; ++j) {
-                    if (j < n_own) {   // wave-uniform
-                        const int f = (ROWS ? 1 : 0) + j - JROW;
-                        const double av[4] = {fc[f][0].x, fc[f][0].y, fc[f][1].x, fc[f][1].y};
+                for (int s2 = 0; s2 < 4; ++s2) {
 #pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2)
-                            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], Bk[b_off[j] + s2 * SPS], acc[j], 0, 0, 0);
+                    for (int j = 0; j < JMAX; ++j) {
+                        const int f = (ROWS && j < JROW) ? 0 : (ROWS ? 1 : 0) + j - JROW;
+                        const double2 ah = fc[f][s2 >> 1];
+                        const double av = (s2 & 1) ? ah.y : ah.x;
+                        if (j < JMAX_ALL || j < n_own)     // (compile-time true except for the last dealt tile)
+                            acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[s2][j], acc[j], 0, 0, 0);
                     }
                 }
             }
@@ -889,28 +900,23 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
                     if (act[k]) sa[k] = *reinterpret_cast<const double2 *>(An + gAo[k]);
             }
         }
-        // one power-of-two scale for the slab: exponent of its largest entry
-        double mx = 0.0;
+        // One power-of-two scale for the slab: the exponent of its largest entry - read off the HIGH words alone (entries
+        // are non-negative, so the sign-stripped high 32 bits order them as the values do, and a NaN / infinity has the
+        // largest exponent field of all): 32-bit maxima and DPP moves instead of 28 fp64 compare-and-select pairs and
+        // six cross-lane round trips per wavefront and step.  (A largest entry below 2^-1022 counts as zero: no scale.)
+        int hmax = 0;
 #pragma unroll
         for (int j = 0; j < JMAX; ++j)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const double v = (j < n_own) ? acc[j][q] : 0.0;
-                mx = (v > mx || v != v) ? v : mx;
-            }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const double o = __shfl_xor(mx, m, 64);
-            mx = (o > mx || o != o) ? o : mx;
-        }
-        if (lane == 0) atomicMax(&smax[which], (unsigned long long)__double_as_longlong(mx));
+            for (int q = 0; q < 4; ++q)
+                if (j < JMAX_ALL || j < n_own) hmax = max(hmax, __double2hiint(acc[j][q]) & 0x7fffffff);
+        hmax = wave_max_i32_dpp(hmax);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int *>(&smax[which]), (unsigned int)hmax);
         __syncthreads();   // also: every wavefront has finished reading the slab
-        const double m = __longlong_as_double((long long)smax[which]);
+        const int field = (int)(*reinterpret_cast<const unsigned int *>(&smax[which]) >> 20);
         if (tid == 0) smax[which ^ 1] = 0ull;
         which ^= 1;
-        int e = 0;
-        (void)frexp(m, &e);
-        e = (m > 0.0 && m < INFINITY) ? e : 0;
+        const int e = (field > 0 && field < 0x7ff) ? field - 1022 : 0;   // frexp's exponent: largest entry in [2^(e-1), 2^e)
 #pragma unroll
         for (int j = 0; j < JMAX; ++j)
             if (j < n_own) {
@@ -919,6 +925,16 @@ __global__ __launch_bounds__(BS_WAVES * 64) void k_big_propagate_s(BigArgs a, co
             }
         ex += cex_cur + e;
         __syncthreads();
+        if constexpr (DIRECT_A && NT % 3 != 0) {   // the next token's panels 0 and 1 sit in sets NT % 3 and (NT + 1) % 3
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double2 p0 = fr[NT % 3][f][h], p1 = fr[(NT + 1) % 3][f][h];
+                    fr[0][f][h] = p0;
+                    fr[1][f][h] = p1;
+                }
+        }
     }
     // results -> level 0: operator block state-major [i][c] (N x NP), or the vector [i] for a first segment
     if (first) {
