@@ -73,7 +73,8 @@ int fail(int code, const std::string &msg)
 
 // k_zpropagate4 caches nothing in LDS while the operator tables of one launch (all parameter sets) fit this many bytes -
 // they then stay in L2 / the Infinity Cache and a step's operands arrive from there a step ahead (IMC_Z4_STREAM=0/1
-// forces the hybrid / the streamed form)
+// forces the hybrid / the streamed form).  With more than one parameter set and the XCD-affine grid the streamed form is
+// used whatever the total (PlanBuilder::z4_streamed).
 constexpr double Z4_STREAM_MAX_BYTES = 32.0e6;
 constexpr size_t STAGE_KERNEL_MAX_BYTES = 1u << 20;   // parameter sets up to this size are fetched by k_stage_params (enqueue)
 constexpr size_t LDS_BUDGET = 160 * 1024 - 1024;   // bytes of LDS a compressed-path workgroup may use
@@ -144,6 +145,7 @@ struct Ctx {
                               // (measured at 10 states: 106 vs 108 us and 113.5 vs 116 us per evaluation; at 20 states 54 vs 52.5 us for
                               // the table - 2197 wavefronts of 125 MFMAs in the depth 7-9 launch - so pairs stay), 0 = never, 1 = always
                               // (IMC_TABLE_TRIPLES)
+    bool xcd_affine = true;   // k_zpropagate4: a parameter set's workgroups all on one XCD when B is 2, 4 or a multiple of 8 (IMC_XCD_AFFINE=0: off)
     int fuse_tail = 1;        // the chunk's last workgroup finishes the chunk (zip3_tail) instead of k_chain launches: 1 = where a chunk is
                               // at most four workgroups (one in-wavefront fold; measured: 100 x 1e6 columns -1.5 us, and +6 us at 13
                               // workgroups of 20 states, where the chain's twenty parallel wavefronts win), 2 = wherever possible, 0 = never (IMC_FUSE_TAIL)
@@ -198,6 +200,7 @@ int ensure_ctx()
     if (const char *fh = std::getenv("IMC_FUSE_HEAD")) g.fuse_head = std::atoi(fh) != 0;
     if (const char *tt = std::getenv("IMC_TABLE_TRIPLES")) g.table_triples = std::atoi(tt) != 0 ? 1 : 0;
     if (const char *ft = std::getenv("IMC_FUSE_TAIL")) g.fuse_tail = std::max(0, std::min(2, std::atoi(ft)));
+    if (const char *xa = std::getenv("IMC_XCD_AFFINE")) g.xcd_affine = std::atoi(xa) != 0;
     if (const char *zs = std::getenv("IMC_Z4_STREAM")) { const int v = std::atoi(zs); if (v >= -1 && v <= 1) g.z4_stream = v; }
     g.pid = me;
     g.ready = true;
@@ -826,6 +829,16 @@ struct PlanBuilder {
     std::vector<HostLevel> hl;          // stitch hierarchy, level 0 = propagate output
     std::vector<int32_t> final_vec;     // chunk -> its single remaining unit at the last level (-1: empty chunk)
 
+    // k_zpropagate4 on the streamed table (nothing cached in LDS)?  With the XCD-affine grid (enqueue) an XCD reads one or
+    // two parameter sets' tables at a time whatever B is, and the streamed form then beat the hybrid one at every
+    // dictionary level and every B measured (profiles/r03_d_affine_levels.txt); without it, while all tables of the launch
+    // fit the L2s.
+    static bool z4_streamed(double tables_bytes, int n_sets)
+    {
+        if (g.z4_stream >= 0) return g.z4_stream == 1;
+        return (g.xcd_affine && n_sets > 1) || tables_bytes <= Z4_STREAM_MAX_BYTES;
+    }
+
     // hand-off head of a group, in stream elements: ~R1_HEAD_COLUMNS alignment columns
     size_t handoff_head(const Group &gr) const
     {
@@ -887,7 +900,7 @@ struct PlanBuilder {
                         double maxtok = 0.0;
                         for (int f : kv.second) maxtok = std::max(maxtok, (double)chunks[f]->ntok[l]);
                         // (up to 12 states two workgroups of the global-table kernel share a CU: twice the slots, 1.85x the step)
-                        const bool two_per_cu = !fits && kc->NP <= 12 && table_bytes <= Z4_STREAM_MAX_BYTES;
+                        const bool two_per_cu = !fits && kc->NP <= 12 && z4_streamed(table_bytes, B);
                         const double n_ch = (double)kv.second.size(), slots = (double)g.cus * Z2SLOTS * (two_per_cu ? 2.0 : 1.0);
                         auto scan_time = [&](double fixed_us, double step_us) {
                             if (two_per_cu) step_us *= 1.85;
@@ -921,13 +934,19 @@ struct PlanBuilder {
                             // (hybrid form; the streamed form - tables of the launch cache resident - runs every step
                             // from the global table at ~6 % over the LDS-table kernel's step: measured at config[1])
                             const double cold_pen = table_bytes / B <= 3.6e6 ? 0.11 : 0.17;
-                            const bool streamed = g.z4_stream == 1 || (g.z4_stream < 0 && table_bytes <= Z4_STREAM_MAX_BYTES);
+                            const bool streamed = z4_streamed(table_bytes, B);
                             // (table: one ~4.5 us launch per depth, or one ~5.7 us launch per pair of depths)
                             // (measured round 3: the first launch - it fetches the parameters - ~13 us, the others ~7.5)
-                            const double t_table = g.table_pairs ? 13.0 + (std::ceil(depths / 2.0) - 1.0) * 7.5 : 6.0 + depths * 4.9;
+                            double t_table = g.table_pairs ? 13.0 + (std::ceil(depths / 2.0) - 1.0) * 7.5 : 6.0 + depths * 4.9;
+                            // ... which is latency; B tables of A operators are also two reads and a write of an operator per
+                            // token and parameter set, at ~2.8 TB/s (measured round 3, 64 sets: 4096- against 512-token tables)
+                            t_table += std::max(0.0, table_bytes * 3.0 / 2.8e6 - 0.5 * t_table);
                             cost = t_table + scan_time(8.0, t_step * (streamed ? 1.06 : 1.0 + cold_pen * cold));
                         }
                         if (g.blocked_variant == 5 && !fits) cost *= 1e-3;      // tests: the hybrid table wherever it is possible
+                        if (std::getenv("IMC_DEBUG_LEVELS"))
+                            std::fprintf(stderr, "[imc] level %d alphabet %d %s: model %.1f us\n", l, A,
+                                         fits ? "LDS table" : two_per_cu ? "global table, 2 per CU" : "global table", cost);
                         if (cost < best) { best = cost; best_l = l; }
                         continue;
                     }
@@ -1053,7 +1072,7 @@ struct PlanBuilder {
                     // (measured at 10 states, 100 x 1e6 columns: 500 workgroups of 44-token segments 102 us, 200 workgroups
                     // of 104-token segments 113 us).
                     const bool two_per_cu = gr.zip4 && kc->use3() && kc->NP <= 12 &&
-                                            (double)B * (gr.A + 1) * kc->tok_doubles * 8.0 <= Z4_STREAM_MAX_BYTES;
+                                            z4_streamed((double)B * (gr.A + 1) * kc->tok_doubles * 8.0, B);
                     const double rows = (double)g.cus * Z2WAVES * 4 * (two_per_cu ? 2.0 : 1.0);
                     const double rb = kc->NP / 4.0;
                     // per wavefront-step (4 segments): DPP/VALU form measured ~2900 at N=20; the MFMA form issues
@@ -1359,7 +1378,7 @@ struct PlanBuilder {
                 for (int z = 0; z < gr.A; ++z) ids[z] = (uint16_t)z;
                 std::stable_sort(ids.begin(), ids.end(), [&](uint16_t x, uint16_t y) { return cnt[x] > cnt[y]; });
                 const double tables = (double)B * (gr.A + 1) * kc->tok_doubles * 8.0;
-                gr.stream_table = g.z4_stream == 1 || (g.z4_stream < 0 && tables <= Z4_STREAM_MAX_BYTES);
+                gr.stream_table = z4_streamed(tables, B);
                 gr.n_hot = gr.stream_table ? 0 : std::min(gr.A, kc->zip4_max_hot(gr.A, LDS_BUDGET));
                 gr.hot.assign(ids.begin(), ids.begin() + gr.n_hot);
                 e = up((void **)&gr.d_hot, gr.hot.data(), gr.hot.size() * sizeof(uint16_t));
@@ -1682,6 +1701,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out, bool allow_tail = true)
         a.A = gr.A; a.tok_left = gr.zip ? gr.dict->d_left : nullptr; a.tok_right = gr.zip ? gr.dict->d_right : nullptr;
         if (gr.big) {
             BigArgs ba;
+            ba.n_phases = 0;
             ba.tail = nullptr; ba.tailX = nullptr; ba.tailE = nullptr; ba.tail_arrive = nullptr; ba.tail_out = nullptr; ba.tail_stride = 0; ba.n_chunks = p->n_chunks;
             ba.segs = p->d_segs; ba.seg_ids = gr.d_seg_ids; ba.seg_vec0 = gr.d_seg_out; ba.blocks = nullptr;
             ba.n_group_segs = (uint32_t)gr.seg_ids.size(); ba.n_vecs_total = p->n_vecs;
@@ -1767,6 +1787,7 @@ int enqueue(Plan *p, hipStream_t stream, double *out, bool allow_tail = true)
             else { lp[2] = gr.seglen; lp[3] += gr.vsteps * (uint64_t)B; }
         } else if (gr.zip2) {
             BigArgs ba;
+            ba.n_phases = 0;
             ba.tail = nullptr; ba.tailX = nullptr; ba.tailE = nullptr; ba.tail_arrive = nullptr; ba.tail_out = nullptr; ba.tail_stride = 0; ba.n_chunks = p->n_chunks;
             ba.segs = p->d_segs; ba.seg_ids = nullptr; ba.seg_vec0 = nullptr; ba.blocks = gr.d_blocks;
             ba.n_group_segs = (uint32_t)gr.blocks.size(); ba.n_vecs_total = p->n_vecs;
@@ -1834,8 +1855,24 @@ int enqueue(Plan *p, hipStream_t stream, double *out, bool allow_tail = true)
                     attr4 = true;
                 }
                 IMC_MARK_A();
-                hipLaunchKernelGGL(scan, dim3(ba.n_group_segs, (unsigned)B), dim3(Z2WAVES * 64),
-                                   kc->zip4_lds(gr.A, gr.n_hot), stream, ba);
+                // XCD-affine grid (BigArgs::n_phases): with the two-dimensional grid every XCD's L2 sees the tables of all
+                // B parameter sets
+                dim3 scan_grid(ba.n_group_segs, (unsigned)B);
+                if (g.xcd_affine && B > 1) {
+                    int first = 0, wg = 0;
+                    auto phase = [&](int sets, int n_sets_total) {
+                        ba.ph_begin[ba.n_phases] = wg; ba.ph_first[ba.n_phases] = first; ba.ph_sets[ba.n_phases] = sets;
+                        ++ba.n_phases;
+                        const int nb = (int)ba.n_group_segs;
+                        wg += sets >= 8 ? 8 * nb * (n_sets_total / 8) : 8 * ((nb + 8 / sets - 1) / (8 / sets));
+                        first += n_sets_total;
+                    };
+                    if (B >= 8) phase(8, B / 8 * 8);
+                    for (int sets : {4, 2, 1})
+                        if ((B % 8) & sets) phase(sets, sets);
+                    scan_grid = dim3((unsigned)wg);
+                }
+                hipLaunchKernelGGL(scan, scan_grid, dim3(Z2WAVES * 64), kc->zip4_lds(gr.A, gr.n_hot), stream, ba);
                 note(std::string("k_zpropagate4<") + std::to_string(NP / 4) + (gr.wide_tokens ? ",16" : "") + (gr.stream_table ? ",streamed>" : ">") + strm);
                 lp[4] = gr.seglen; lp[5] += gr.vsteps * (uint64_t)B; lp[6] += gr.stream_len; lp[7] = std::max(lp[7], (uint64_t)gr.A);
                 HIP_TRY(hipGetLastError());

@@ -77,6 +77,14 @@ struct BigArgs {
     int *tail_arrive;             // [B][n_chunks] arrival counters (zero between evaluations: the last arriver resets its own)
     double *tail_out;             // [B][n_chunks] log-likelihoods (device memory or the mapped result slots on the host)
     int tail_stride, n_chunks;
+    // k_zpropagate4's workgroup -> (parameter set, block) map.  n_phases = 0: grid (blocks, B).  Otherwise a one-dimensional
+    // grid, dealt round-robin over the eight XCDs by the dispatcher (workgroup L runs on XCD L % 8), cut into phases
+    // that each load all XCDs evenly: first the B / 8 * 8 sets of the "eight at a time" phase - set L % 8 + 8 * round
+    // on XCD L % 8, all of a set's blocks on that one XCD - then, for the remaining B % 8 = 4 a + 2 b + c sets, a phase of
+    // four sets on two XCDs each, one of two sets on four XCDs each, one of a single set on all eight.  A set's operator
+    // table is then read through the L2 of one (two, four) XCDs, and an XCD works on one or two sets at a time, instead
+    // of every XCD's 4 MB L2 seeing the tables of all B sets.
+    int n_phases, ph_begin[4], ph_first[4], ph_sets[4];
 };
 
 

@@ -212,12 +212,12 @@ __device__ __forceinline__ void zip3_fold(double (&P)[NT][NT], int &ex, double *
 // exponent has a 128-byte slot): a last arriver that shares an XCD with an earlier one must not find a line in that
 // L2 that was fetched before all of its words were written.
 template <int NT>
-__device__ __forceinline__ void zip3_tail(const BigArgs &a, double (&P)[NT][NT], int &ex, double *X, int *xe, int b, int slot, int lo, int lx)
+__device__ __forceinline__ void zip3_tail(const BigArgs &a, double (&P)[NT][NT], int &ex, double *X, int *xe, int b, int bx, int slot, int lo, int lx)
 {
     using Geo = Zip3Geom<NT>;
     constexpr int TOK = Geo::TOK;
     __shared__ int s_last;
-    const Z2Tail td = a.tail[blockIdx.x];
+    const Z2Tail td = a.tail[bx];
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = lane >> 4, r = lane & 3;
     const size_t cb = (size_t)b * a.n_chunks + td.chunk;
@@ -469,5 +469,5 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
             }
         }
     }
-    if (a.tail) zip3_tail<NT>(a, P, ex, C, cex, b, slot, lo, lx);
+    if (a.tail) zip3_tail<NT>(a, P, ex, C, cex, b, (int)blockIdx.x, slot, lo, lx);
 }

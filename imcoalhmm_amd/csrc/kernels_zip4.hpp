@@ -480,7 +480,21 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     int *xex = slot_of + a.A + 2;                                      // [Z2SLOTS + 1] the fold's exchange exponents
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.y;
+    int b = (int)blockIdx.y, bx = (int)blockIdx.x;                     // parameter set, block (BigArgs::n_phases)
+    if (a.n_phases > 0) {
+        int ph = 0;
+        while (ph + 1 < a.n_phases && (int)blockIdx.x >= a.ph_begin[ph + 1]) ++ph;
+        const int local = (int)blockIdx.x - a.ph_begin[ph], xcd = local & 7, turn = local >> 3, nb = (int)a.n_group_segs;
+        const int sets = a.ph_sets[ph];
+        if (sets >= 8) {                                               // eight sets at a time, one per XCD
+            b = a.ph_first[ph] + xcd + 8 * (turn / nb);
+            bx = turn % nb;
+        } else {                                                       // sets = 4, 2, 1: each on 8 / sets XCDs
+            b = a.ph_first[ph] + xcd % sets;
+            bx = turn * (8 / sets) + xcd / sets;
+            if (bx >= nb) return;                                      // (workgroup-uniform, before any barrier)
+        }
+    }
     const double *pp = a.params + (size_t)b * a.pstride;
     const double *pi_p = pp;
     const double *Etg = pp + a.PP + (size_t)a.PP * a.PP;
@@ -508,7 +522,7 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     const int lane = tid & 63;
     const int q = lane >> 4, bq = (lane >> 2) & 3, r = lane & 3;
     const int lo = (q * 4 + r) * Geo::NTE, lx = q * 4 + r;
-    const Z2Block blk = a.blocks[blockIdx.x];
+    const Z2Block blk = a.blocks[bx];
     const int slot = (tid >> 6) * 4 + bq;                   // 0..Z2SLOTS-1 within the workgroup
     const bool valid = slot < (int)blk.n;
     const uint32_t seg = blk.seg0 + (valid ? slot : 0);
@@ -722,5 +736,5 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
             }
         }
     }
-    if (a.tail) zip3_tail<NT>(a, P, ex, C, xex, b, slot, lo, lx);
+    if (a.tail) zip3_tail<NT>(a, P, ex, C, xex, b, bx, slot, lo, lx);
 }

@@ -48,7 +48,10 @@
  *   of by the evaluation's first table launch / by each workgroup of a small launch), IMC_TABLE_TRIPLES=0|1 (three
  *   dictionary depths per table launch, one wavefront per token: never / always; default: up to 12 states, where it is 2 % faster), IMC_FUSE_TAIL=0|1|2 (the chunk's
  *   last workgroup finishes the chunk instead of stitch launches: never / chunks of at most four workgroups (default) /
- *   wherever a chunk is at most 32 workgroups; 2 changes results by re-association only)
+ *   wherever a chunk is at most 32 workgroups; 2 changes results by re-association only),
+ *   IMC_XCD_AFFINE=0 (k_zpropagate4 on a plain (blocks, parameter sets) grid: by default its one-dimensional grid puts all
+ *   workgroups of a parameter set on one XCD - two or four for the last B % 8 sets - so that a set's operator table is read
+ *   through one L2 instead of all eight; placement only, every bit of every result is the same)
  *
  * fork(): a child forked AFTER the parent's first imc_* call gets IMC_ERR_HIP from every call (HIP state does not
  * survive fork and nothing of the parent's is touched); fork chain processes first, or use the spawn start method.

@@ -717,3 +717,34 @@ def test_many_chunks_times_many_proposals_plan(oracle, hmm_params):
         for k in (0, 33, 69):
             assert rel_err(per[b][k], oracle.forward_scaled(pis[b], Ts[b], Es[b], chunks[k])) < TOL, (b, k)
     assert np.array_equal(per[0], per[3]) and np.array_equal(per[1], per[70])       # same parameter set, same bits
+
+
+def test_every_number_of_parameter_sets_reaches_every_workgroup(oracle, hmm_params):
+    """k_zpropagate4's XCD-affine grid (BigArgs::n_phases, csrc/kernels_big.hpp): a one-dimensional grid cut into phases -
+    eight parameter sets at a time with one set per XCD, then the remaining B % 8 = 4a + 2b + c sets on two, four and eight
+    XCDs each.  Every B from 1 to 26 (every combination of phases, with and without the eight-at-a-time phase), ragged
+    chunks whose workgroup counts are not multiples of the XCDs per set, global-table kernel forced: every (set, chunk)
+    value against the same set evaluated alone (1e-12: dictionary level and segment length depend on B), three sets against
+    the oracle."""
+    L = _capi.lib()
+    hm = [hmm_params("iso20_t%d" % (b % 3)) for b in range(3)] + [synth.random_hmm(20, 3, seed=4100 + b, stay=0.99) for b in range(23)]
+    chunks = [synth.sample_alignment(*hm[0], m, seed=4200 + k) for k, m in enumerate((1_500_000, 4_500, 33_333, 7_000))]
+    try:
+        _capi.check(L.imc_set_compression(3)); _capi.check(L.imc_set_blocked_kernel(5)); _capi.check(L.imc_dictionary_reset())
+        fw = [Forwarder.from_array(c, 3) for c in chunks]
+        handles = [f.handle for f in fw]
+        alone = np.array([forward_chunks_batch(handles, *(x[None] for x in h), per_chunk=True)[0] for h in hm])
+        assert "k_zpropagate4" in _capi.last_plan()["kernels"], _capi.last_plan()["kernels"]
+        for b in range(3):
+            for k, c in enumerate(chunks):
+                assert rel_err(alone[b][k], oracle.forward_scaled(hm[b][0], hm[b][1], hm[b][2], c)) < TOL, (b, k)
+        for B in range(2, 27):
+            pis, Ts, Es = (np.stack([h[k] for h in hm[:B]]) for k in range(3))
+            per = forward_chunks_batch(handles, pis, Ts, Es, per_chunk=True)
+            plan = _capi.last_plan()
+            assert "k_zpropagate4" in plan["kernels"], plan["kernels"]
+            bad = np.argwhere(np.abs(per - alone[:B]) > 1e-12 * np.abs(alone[:B]))
+            assert bad.size == 0, (B, bad[:4])
+        del fw
+    finally:
+        _capi.check(L.imc_set_compression(1)); _capi.check(L.imc_set_blocked_kernel(4)); _capi.check(L.imc_dictionary_reset())

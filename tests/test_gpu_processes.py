@@ -338,6 +338,10 @@ def test_ab_switches_change_nothing_but_the_schedule(tmp_path):
         outs[(pairs, pack, fuse, triples)] = r.stdout.strip().splitlines()[-1]
     assert len(set(outs.values())) == 1, outs
     assert "k_big_vector" in outs[combos[0]] and "k_big_propagate" in outs[combos[0]]      # both large-N paths were on the route
+    # IMC_XCD_AFFINE=0: k_zpropagate4 on the plain (blocks, B) grid instead of the XCD-affine one - placement only
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600, env=dict(os.environ, IMC_XCD_AFFINE="0"))
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    assert r.stdout.strip().splitlines()[-1] == outs[combos[0]]
     # IMC_FUSE_TAIL (the chunk's last workgroup finishes the chunk instead of k_chain launches; 2 = wherever a chunk is at
     # most 32 workgroups, 0 = never) re-associates the last few products and the final sum: same values to 1e-13, not
     # the same bits
