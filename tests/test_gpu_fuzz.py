@@ -39,6 +39,9 @@ def test_random_dispatch(oracle, case):
     chunks = [_chunk(rng, nsym, x) for x in lens]
     variant = int(rng.choice([2, 3, 4, 5, 5]))           # form of the register-blocked kernel (N <= 24): VALU, MFMA + LDS table,
     stream = int(rng.choice([-1, 0, 1]))                 # k_zpropagate4's table: automatic, LDS-cached hot set, streamed
+    if n <= 24 and rng.random() < 0.3:                   # larger batches: every phase of k_zpropagate4's XCD-affine grid
+        B = int(rng.choice([4, 5, 8, 9, 12, 17]))        # (drawn last: the cases of earlier rounds keep their other draws)
+        hmms = [synth.random_hmm(n, nsym, seed=case * 10 + b, stay=float(rng.choice([0.5, 0.9, 0.999]))) for b in range(B)]
     try:                                                 # automatic, hybrid table wherever possible
         _capi.check(L.imc_set_blocked_kernel(variant))
         _capi.check(L.imc_set_table_streaming(stream))
