@@ -779,6 +779,29 @@ size_t choose_seglen(const std::vector<size_t> &lens, int N, int B, int VPW, dou
 // Cycles per chain step and CU of the mat-vec chain kernel (k_big_vector): NP^2 doubles streamed per step.
 // Measured at N=150, 2048 chains: ~NP^2/3 cycles while one parameter set's table stays within ~6 MB (its share of
 // an XCD's L2), growing by ~3 % per further MB as reads fall through to the Infinity Cache, up to the HBM rate.
+// GEMM chain: cycles (at ~2.2 GHz) a CU needs to advance ONE segment by one step - all column slabs of the segment, chip
+// full.  Measured round 3 on every built tile count below (profiles/r03_e_calib_big.txt: one 1e7-column chunk, all CUs
+// busy): 0.55 us at NP = 32, 1.52 at 48, 2.9 at 64, 9.4 at 96, 15.0 at 112, 33 at 160.  Rounds 1-2 used
+// 0.027 NP^3 + 20000 cycles, fitted at NP = 160 on round 1's kernel: 1.8x too high there and 16x too high at NP = 32, so
+// that 24 < N <= 64 with a handful of chunks x parameter sets took the mat-vec chain (one workgroup per chain, 10-40
+// workgroups on 256 CUs) at 3-9x the GEMM chain's time.
+static double gemm_cu_step_cycles(int np)
+{
+    const int nt = np / 16;
+    double us;
+    switch (nt) {
+    case 2: us = 0.55; break;
+    case 3: us = 1.52; break;
+    case 4: us = 2.9; break;
+    case 6: us = 9.4; break;
+    case 7: us = 15.0; break;
+    case 8: us = 22.4; break;
+    case 9: us = 24.1; break;
+    default: us = 33.0 * (nt / 10.0) * (nt / 10.0) * (nt / 10.0); break;
+    }
+    return us * 2200.0;
+}
+
 static double matvec_step_cycles(double np2, int alphabet)
 {
     const double table_mb = (double)alphabet * np2 * 8.0 / 1.0e6;
@@ -794,7 +817,7 @@ struct HandoffEstimate { int m; double cycles; };
 static HandoffEstimate estimate_handoff(double seglen, double nseg, int B, double head, double np, int nslab, int alphabet, int cus)
 {
     // (a segment's GEMM step is shared by its nslab column-slab workgroups)
-    const double np2 = np * np, t_gemm = 0.027 * np2 * np / nslab + 20000.0;
+    const double np2 = np * np, t_gemm = 1.15 * gemm_cu_step_cycles((int)np) / nslab;   // (a head step of one slab's workgroup)
     const double table_mb = (double)alphabet * np2 * 8.0 / 1.0e6;
     const double bw = table_mb > 128.0 ? 7.0e12 : table_mb > 16.0 ? 8.6e12 : 15.0e12;   // bytes/s: HBM, Infinity Cache, L2
     HandoffEstimate best{0, 1e300};
@@ -884,8 +907,6 @@ struct PlanBuilder {
                         const bool hybrid_ok = !fits && kc->zip4 && g.blocked_variant >= 4 && max_hot >= 8 && !o0->tok_count[l].empty() &&
                                                table_bytes <= 2.0e9;
                         if (!fits && !hybrid_ok) continue;
-                        double toks = 0.0;
-                        for (int f : kv.second) toks += (double)chunks[f]->ntok[l];
                         int passes = 0;
                         {
                             std::map<int, int> per_depth;
@@ -956,8 +977,8 @@ struct PlanBuilder {
                     for (int f : kv.second) toks += (double)chunks[f]->ntok[l];
                     const double n3 = (double)kc->NP * kc->NP * kc->NP;
                     double c_tab, c_main;   // cycles
-                    if (big) {   // one GEMM per step per workgroup (~0.027 n^3 cycles measured at N=150), table built by depth
-                        const double gemm = 0.027 * n3 + 20000.0;
+                    if (big) {   // one GEMM per step per workgroup, table built by depth
+                        const double gemm = gemm_cu_step_cycles(kc->NP);
                         c_tab = ((o0->alphabet[l] - S) / (double)g.cus + 12.0) * gemm;   // one workgroup per token, ~12 depth launches
                         c_main = std::max(16.0, toks * B / (double)g.cus) * gemm;
                         double lmax = 0.0;   // or the mat-vec chain kernel, when no chunk needs splitting
@@ -1027,6 +1048,17 @@ struct PlanBuilder {
                 const size_t per_cu = std::max<size_t>(1, std::min<size_t>(LDS_BUDGET / kc->big_lds, (size_t)32 / (size_t)kc->G));
                 const size_t target = std::max<size_t>(1, (size_t)g.cus * per_cu / ((size_t)B * kc->big_nslab));
                 gr.seglen = std::max<size_t>(16, round_up((total + target - 1) / target, 16));
+                // Chunks are cut one by one (ceil(L / seglen) segments each): with several chunks the sum can exceed the
+                // target by a few segments - and one segment more than the machine holds is a second ROUND of workgroups,
+                // twice the time (measured round 3 at 150 states, 3 x 3e6 columns: 129 segments for 128 slots, 201 ms
+                // against 103).  Lengthen the segments until the launch fits.
+                {
+                    auto count = [&](size_t sl) { size_t c = 0; for (size_t L : lens) c += (L + sl - 1) / sl; return c; };
+                    size_t nonempty = 0;
+                    for (size_t L : lens) nonempty += L > 0;
+                    if (nonempty <= target)            // (more chunks than slots: rounds are unavoidable)
+                        for (int it = 0; it < 65536 && count(gr.seglen) > target; ++it) gr.seglen += 16;
+                }
                 // ... unless there are so many (chunk, parameter set) chains that no chunk needs splitting: then
                 // the mat-vec chain kernel streams NP^2 doubles per step instead of a GEMM (measured at N=150, 64 x 32
                 // chains: 8900 cycles per step per CU, i.e. ~12 TB/s of operator reads over the whole chip)
@@ -1034,7 +1066,7 @@ struct PlanBuilder {
                 for (size_t L : lens) lmax = std::max(lmax, L);
                 const double np2 = (double)kc->NP * kc->NP, per_cu_steps = (double)total * B / (double)g.cus;
                 const double cost_vec = std::max((double)lmax * (np2 / 4.5 + 1500.0), per_cu_steps * matvec_step_cycles(np2, gr.A));
-                double cost_gemm = std::max(16.0, per_cu_steps) * (0.027 * np2 * kc->NP + 20000.0);
+                double cost_gemm = std::max(16.0, per_cu_steps) * gemm_cu_step_cycles(kc->NP);
                 if (g.rank1_handoff && !g.seg_override && gr.seglen >= R1_MIN_SEGLEN) {   // GEMM heads + mat-vec tails
                     const HandoffEstimate he = estimate_handoff((double)gr.seglen, std::max(1.0, (double)total / gr.seglen), B,
                                                                 (double)handoff_head(gr), kc->NP, kc->big_nslab, gr.A, g.cus);
@@ -1108,7 +1140,6 @@ struct PlanBuilder {
                     for (size_t u = 1; u <= 8; ++u)
                         cands.push_back(std::max<size_t>(16, round_up((lmax + Z2SLOTS * u - 1) / (Z2SLOTS * u), Z2GRAN)));
                     for (size_t sg : cands) {
-                        const double used = rows_used(sg);
                         // per round of workgroups: the main loop, plus the table rebuild and the 5-level in-kernel fold
                         // (table: the VALU form builds token by token; the MFMA form one dictionary depth per pass,
                         // ~10 depths; with the hybrid table a workgroup only copies its hot set from L2)
@@ -1555,7 +1586,9 @@ int build_plan(const imc_obs *const *chunks, int n_chunks, int N, int S, int B, 
         for (int f = 0; f < n_chunks; ++f) total += (double)chunks[f]->L;
         bool tokens = g.compression != 0;   // on the raw column stream the vector kernel still wins up to N=40 (no padding to 16s)
         for (int f = 0; f < n_chunks; ++f) tokens = tokens && chunks[f]->dict && chunks[f]->nsym == S;
-        prefer_gemm = total / n_chunks >= 2.0e5 && (tokens || N > 40);
+        // (round 3: 1e6 columns in all and 5e3 per chunk on average - it used to be 2e5 per chunk, and 100 chunks of 1e5
+        // columns then ran on the LDS-table vector kernels at 4-9x the GEMM chain's time, profiles/r03_e_calib_big.txt)
+        prefer_gemm = total >= 1.0e6 && total / n_chunks >= 5.0e3 && (tokens || N > 40);
     }
 
     KernelChoice *kc = choose_kernel(N, prefer_gemm);

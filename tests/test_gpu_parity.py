@@ -387,9 +387,11 @@ def test_matvec_chain_kernel_large_n(oracle, n, mode):
 
 @pytest.mark.parametrize("n", [32, 41, 64])
 def test_matvec_chain_kernel_mid_n_many_chunks(oracle, n):
-    """24 < N <= 64: with many long chunks x proposals the planner drops the transfer operators altogether."""
+    """24 < N <= 64: with many long chunks x proposals the planner drops the transfer operators altogether.  (640 chains:
+    with round 3's measured GEMM-chain step costs - profiles/r03_e_calib_big.txt - the 80 chains this test had until
+    then are rightly put on the GEMM chain, which is 3-9x faster there.)"""
     set_zip(1)
-    hmms = [synth.random_hmm(n, 3, seed=77 * n + b, stay=0.95) for b in range(2)]
+    hmms = [synth.random_hmm(n, 3, seed=77 * n + b, stay=0.95) for b in range(16)]
     pis, Ts, Es = (np.stack([h[k] for h in hmms]) for k in range(3))
     chunks = [compressible(210_000 + 1000 * k, seed=n * 17 + k) for k in range(40)]
     fw = [Forwarder.from_array(c, 3) for c in chunks]
@@ -403,7 +405,7 @@ def test_matvec_chain_kernel_mid_n_many_chunks(oracle, n):
     finally:
         set_zip(1)
     assert np.max(np.abs(got / ref - 1)) < TOL
-    for b, k in ((0, 0), (1, 39)):
+    for b, k in ((0, 0), (1, 39), (15, 20)):
         assert rel_err(got[b][k], oracle.forward_scaled(pis[b], Ts[b], Es[b], chunks[k])) < TOL
 
 
