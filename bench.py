@@ -145,7 +145,7 @@ def read_profile(lib):
     return ms_p.value / max(n_p.value, 1), ms_s.value / max(n_s.value, 1)
 
 
-def timed_steps(lib, step, steps, warmup, fence):
+def timed_steps(lib, step, steps, warmup, fence, agree=None):
     """W untimed + K timed calls of step(), bracketed by fence(); HIP-event kernel timing over the timed region.
     (Checked in round 3: the events cost the timed region nothing measurable - 0.2852 ms per step without them, 0.2835
     with, same process - although a rocprofv3 timeline shows ~5 us queue gaps around an event-bracketed kernel: those
@@ -156,9 +156,15 @@ def timed_steps(lib, step, steps, warmup, fence):
     # evaluation at 20 states / 3e7 columns, 113.6 -> 107 us at 10 states / 100 x 1e6, profiles/r03_f_clock_ramp.txt - and
     # W = 5 steps of 0.3 ms end inside that ramp.  The quantity of interest is the rate an optimiser's thousands of
     # consecutive evaluations see.
+    # (Several ranks: step() holds a collective, so every rank must make the same number of calls - the ranks agree after
+    # each one whether anybody still needs more: `agree`.)
     t_cond = time.perf_counter()
-    while CONDITION_MS > 0 and (time.perf_counter() - t_cond) * 1e3 < CONDITION_MS:
+    more = CONDITION_MS > 0
+    while more:
         value = step()
+        more = (time.perf_counter() - t_cond) * 1e3 < CONDITION_MS
+        if agree is not None:
+            more = agree(more)
     for _ in range(warmup):
         value = step()
     lib.imc_profile_enable(1)
@@ -321,7 +327,13 @@ def main():
                 return float(ll.forward_params_batch(pis, Ts, Es, reduce=False)[0])
             return ll.forward_params(pi, T, E, reduce=False)
         _, alone_elapsed, _, _ = timed_steps(lib, step_alone, args.steps, args.warmup, torch.cuda.synchronize)
-    value, elapsed, k_ms, s_ms = timed_steps(lib, step, args.steps, args.warmup, fence)
+    def agree(flag):                                   # any rank still conditioning? (one tiny collective per call)
+        rdev_ = torch.device("cpu") if args.rehearse_on_one_gpu else dev
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=rdev_)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(int(t.item()))
+
+    value, elapsed, k_ms, s_ms = timed_steps(lib, step, args.steps, args.warmup, fence, agree if world > 1 else None)
     plan = _capi.last_plan()
     rank1_stats = None
     if world == 1 and args.batch == 1:     # one extra synchronous evaluation: the hand-off counters are read back there
