@@ -541,7 +541,17 @@ def extra_configs(lib, d, data, fence):
     run("isolation-model 10 states, examples/example_data.fa hg18/pantro2, %d columns (BASELINE config[0], on the GPU)" % pair.size,
         fw, lambda: _capi.forward1(h, 1, pi10, T10, E10), float(pair.size), 1, 200, 20)
     res[-1]["us_per_evaluation"] = plain_latency_us(lambda: _capi.forward1(h, 1, pi10, T10, E10), 300)
-    del fw, h
+    # what a caller of the reference's interface sees: Likelihood(model, forwarders)(theta) = host-side (pi, T, E)
+    # construction (models.py; native for the small state spaces, include/imcoal_model.h) + the forward pass
+    from imcoalhmm_amd import models as _models
+    from imcoalhmm_amd.likelihood import Likelihood as _Likelihood
+    lik = _Likelihood(_models.IsolationModel(10), fw, recompress=False)
+    theta = np.array((0.001, 1000.0, 0.4))
+    counter = iter(range(10 ** 9))
+    res[-1]["end_to_end_us_per_likelihood_call"] = plain_latency_us(lambda: lik(theta * (1.0 + 1e-6 * next(counter))), 300)
+    counter = iter(range(10 ** 9))
+    res[-1]["model_build_us_per_call"] = plain_latency_us(lambda: lik.model.build_hidden_markov_model(theta * (1.0 + 1e-6 * next(counter))), 300)
+    del fw, h, lik
     # the authors' own data scale: 100 files of 1 Mbp (simulations/isolation-model/simulate.sh:11), 10 states, one theta
     t0 = time.time()
     _capi.check(lib.imc_dictionary_reset())

@@ -74,6 +74,11 @@ SIGNATURES = [
     ("imc_obs_recompress", ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     ("imc_last_plan", ctypes.c_int, [_u64p]),
     ("imc_last_kernels", ctypes.c_char_p, []),
+    # include/imcoal_model.h (host-side helper, no device)
+    ("imc_model_transitions", ctypes.c_int,
+     [ctypes.c_int, ctypes.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, ctypes.c_int, _i32p, ctypes.c_int, _i32p, _dp, _dp, _dp, _dp,
+      _dp, _dp, ctypes.c_int]),
+    ("imc_model_expm", ctypes.c_int, [ctypes.c_int, _dp, _dp]),
 ]
 
 _lib = None

@@ -10,8 +10,9 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(PKG, "csrc", "imcoal_fwd.hip")
 HDR = os.path.join(os.path.dirname(PKG), "include", "imcoal_fwd.h")
-DEPS = [SRC, HDR] + [os.path.join(PKG, "csrc", f) for f in
-                     ("kernels_plain.hpp", "kernels_zip.hpp", "kernels_stitch.hpp", "kernels_big.hpp", "kernels_zip2.hpp", "kernels_zip3.hpp", "kernels_zip4.hpp", "pair_dict.hpp", "obs_io.hpp")]
+DEPS = [SRC, HDR, os.path.join(os.path.dirname(PKG), "include", "imcoal_model.h")] + [os.path.join(PKG, "csrc", f) for f in
+                     ("kernels_plain.hpp", "kernels_zip.hpp", "kernels_stitch.hpp", "kernels_big.hpp", "kernels_zip2.hpp", "kernels_zip3.hpp", "kernels_zip4.hpp", "pair_dict.hpp", "obs_io.hpp",
+                      "model_host.hpp")]
 LIB = os.path.join(PKG, "libimcoal_fwd.so")
 
 

@@ -49,6 +49,8 @@
 #include "kernels_zip3.hpp"
 #include "kernels_zip4.hpp"
 #include "pair_dict.hpp"
+#include "model_host.hpp"
+#include "../../include/imcoal_model.h"
 #include "obs_io.hpp"
 
 namespace {
@@ -2590,6 +2592,58 @@ int imc_last_plan(uint64_t *out8)
     std::lock_guard<std::mutex> lk(g_mu);
     if (!out8) return fail(IMC_ERR_ARG, "out8 is null");
     for (int k = 0; k < 8; ++k) out8[k] = g.last_plan[k];
+    return IMC_OK;
+}
+
+// ---- host-side model construction (include/imcoal_model.h; no device, no context) ----
+int imc_model_transitions(int n_systems, int n_intervals, const int32_t *space_size, const int32_t *cls_off,
+                          const int32_t *cls_idx, const int32_t *piece_q, const int32_t *piece_proj, int n_q,
+                          const int32_t *q_size, int n_proj, const int32_t *proj_off, const double *proj, const double *Q,
+                          const double *dt, const double *start, double *pi, double *T, int n_threads)
+{
+    if (n_systems < 0 || n_intervals < 1 || n_q < 1 || !space_size || !cls_off || !cls_idx || !q_size || !Q || !start || !pi || !T ||
+        (n_intervals > 1 && (!piece_q || !piece_proj || !dt)))
+        return fail(IMC_ERR_ARG, "imc_model_transitions: bad arguments");
+    std::vector<int32_t> q_off((size_t)n_q);
+    int stride = 0;
+    for (int k = 0; k < n_q; ++k) {
+        if (q_size[k] < 1) return fail(IMC_ERR_ARG, "imc_model_transitions: rate matrix of order < 1");
+        q_off[k] = stride;
+        stride += q_size[k] * q_size[k];
+    }
+    for (int i = 0; i + 1 < n_intervals; ++i) {
+        if (piece_q[i] < 0 || piece_q[i] >= n_q || piece_proj[i] >= n_proj || (piece_proj[i] >= 0 && (!proj || !proj_off)))
+            return fail(IMC_ERR_ARG, "imc_model_transitions: piece index out of range");
+    }
+    for (int i = 0; i < n_intervals; ++i)
+        for (int k = cls_off[3 * i]; k < cls_off[3 * i + 3]; ++k)
+            if (cls_idx[k] < 0 || cls_idx[k] >= space_size[i]) return fail(IMC_ERR_ARG, "imc_model_transitions: class index outside its state space");
+    imc_model::Structure st{n_intervals, space_size, cls_off, cls_idx, piece_q, piece_proj, n_q, q_size, q_off.data(), stride, proj_off, proj};
+    const size_t n = (size_t)n_intervals, s0 = (size_t)space_size[0];
+    const int threads = std::max(1, std::min(std::min(n_threads, n_systems), 64));
+    std::vector<std::string> errs((size_t)threads);
+    auto work = [&](int t) {
+        for (int b = t; b < n_systems && errs[t].empty(); b += threads)
+            errs[t] = imc_model::transitions_one(st, Q + (size_t)b * stride, dt ? dt + (size_t)b * (n - 1) : nullptr, start + (size_t)b * s0,
+                                                 pi + (size_t)b * n, T + (size_t)b * n * n);
+    };
+    if (threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread &th : pool) th.join();
+    }
+    for (const std::string &e : errs)
+        if (!e.empty()) return fail(IMC_ERR_ARG, e);
+    return IMC_OK;
+}
+
+int imc_model_expm(int n, const double *A, double *out)
+{
+    if (n < 1 || !A || !out) return fail(IMC_ERR_ARG, "imc_model_expm: bad arguments");
+    std::vector<double> work;
+    if (!imc_model::expm(A, out, n, work)) return fail(IMC_ERR_ARG, "imc_model_expm: singular Pade denominator");
     return IMC_OK;
 }
 

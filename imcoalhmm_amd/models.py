@@ -24,11 +24,13 @@ with either implementation; ``build_batch(thetas)`` is the additive population e
 Parity is pinned: tests/test_models_cpu.py compares against (pi, T, E) produced by the reference's
 own model classes (tests/golden/model_golden.npz, generator committed beside it).
 """
+import ctypes
 import math
+import os
 from collections import deque
 
 import numpy as np
-from scipy.linalg import expm
+from scipy.linalg import expm as _scipy_expm
 
 __all__ = [
     "exp_break_points", "trunc_exp_break_points", "uniform_break_points", "psmc_break_points",
@@ -289,7 +291,7 @@ class _Through(object):
                     group = members.setdefault(Q.shape[0], [])
                     slots[key] = len(group)
                     group.append(Q * dt)
-        self.stacks = {size: expm(np.stack(group)) for size, group in members.items()}
+        self.stacks = {size: _scipy_expm(np.stack(group)) for size, group in members.items()}
         self._gathered = {}
         self.where = []            # per interval: (size, positions (B,), projection)
         for i in range(len(systems[0].pieces)):
@@ -312,6 +314,139 @@ class _Through(object):
         return stack[pos[:, None], rows[None, :]] @ proj[:, cols]
 
 
+# ---------------------------------------------------------------------------------------------
+# native path (csrc/model_host.hpp behind include/imcoal_model.h): the same recursion in C++ for
+# small state spaces, where the ~40 numpy calls per interval - not the arithmetic - are the cost
+# ---------------------------------------------------------------------------------------------
+NATIVE_MAX_SPACE = 32           # larger spaces (the 94-state migration space) stay on numpy / BLAS
+_native = {"lib": None, "tried": False, "structures": {}}
+
+
+def _native_lib():
+    """libimcoal_fwd.so if it is there (host-only entry points: no device is touched), else None -
+    the numpy path computes the same numbers.  IMC_MODEL_NATIVE=0 switches the native path off."""
+    if not _native["tried"]:
+        _native["tried"] = True
+        if os.environ.get("IMC_MODEL_NATIVE", "1") != "0":
+            try:
+                from . import _capi
+                _native["lib"] = _capi.lib()
+            except Exception:            # library not built: numpy path
+                _native["lib"] = None
+    return _native["lib"]
+
+
+def expm(A):
+    """``scipy.linalg.expm`` for stacks and large matrices; one small matrix goes through the
+    library's [13/13] Pade routine (a 4 x 4 scipy call costs 60 us of Python)."""
+    A = np.asarray(A, dtype=np.float64)
+    lib = _native_lib() if A.ndim == 2 and A.shape[0] <= NATIVE_MAX_SPACE else None
+    if lib is None:
+        return _scipy_expm(A)
+    A = np.ascontiguousarray(A)
+    out = np.empty_like(A)
+    dp = ctypes.POINTER(ctypes.c_double)
+    if lib.imc_model_expm(A.shape[0], A.ctypes.data_as(dp), out.ctypes.data_as(dp)) != 0:
+        return _scipy_expm(A)
+    return out
+
+
+def _native_structure(system):
+    """The parameter-independent part of a PiecewiseCTMC as the int32 arrays of imc_model_transitions,
+    cached per (state spaces, piece pattern, projections)."""
+    q_index, piece_q, projs, piece_proj = {}, [], [], []
+    for Q, _, proj in system.pieces:
+        piece_q.append(q_index.setdefault(id(Q), len(q_index)))
+        if proj is None:
+            piece_proj.append(-1)
+        else:
+            for k, known in enumerate(projs):
+                if known is proj:
+                    piece_proj.append(k)
+                    break
+            else:
+                projs.append(proj)
+                piece_proj.append(len(projs) - 1)
+    key = (tuple(id(sp) for sp in system.spaces), tuple(piece_q), tuple(piece_proj), tuple(id(p) for p in projs))
+    st = _native["structures"].get(key)
+    if st is None:
+        spaces = system.spaces
+        if max(sp.size for sp in spaces) > NATIVE_MAX_SPACE:
+            st = False
+        else:
+            lists = [np.asarray(c, dtype=np.int32) for sp in spaces for c in (sp.begin_states, sp.left_states, sp.end_states)]
+            proj_flat = [np.ascontiguousarray(p, dtype=np.float64).ravel() for p in projs]
+            st = {
+                "n": len(spaces),
+                "space_size": np.array([sp.size for sp in spaces], dtype=np.int32),
+                "cls_off": np.concatenate([[0], np.cumsum([len(c) for c in lists])]).astype(np.int32),
+                "cls_idx": np.concatenate(lists).astype(np.int32) if lists else np.zeros(0, dtype=np.int32),
+                "piece_q": np.array(piece_q, dtype=np.int32), "piece_proj": np.array(piece_proj, dtype=np.int32),
+                "n_q": len(q_index),
+                "proj_off": np.concatenate([[0], np.cumsum([len(p) for p in proj_flat])])[:-1].astype(np.int32) if projs else np.zeros(0, dtype=np.int32),
+                "proj": np.concatenate(proj_flat) if projs else np.zeros(0),
+                "keep": (list(spaces), projs),           # the ids in the key stay valid while the entry lives
+            }
+        _native["structures"][key] = st
+    return st, q_index
+
+
+def _native_transitions(systems):
+    lib = _native_lib()
+    if lib is None:
+        return None
+    if len(systems[0].spaces) < 2:          # a single interval: nothing to exponentiate, numpy does it
+        return None
+    st, q_index = _native_structure(systems[0])
+    if not st:
+        return None
+    n, nb = st["n"], len(systems)
+    order = sorted(q_index, key=q_index.get)
+    first = {id(Q): Q for Q, _, _ in systems[0].pieces}
+    q_size = np.array([first[i].shape[0] for i in order], dtype=np.int32)
+    Qs = np.empty((nb, int((q_size.astype(np.int64) ** 2).sum())))
+    dts = np.empty((nb, max(n - 1, 0)))
+    s0 = int(st["space_size"][0])
+    starts = np.empty((nb, s0))
+    q_pos = np.concatenate([[0], np.cumsum(q_size.astype(np.int64) ** 2)])
+    piece_q = st["piece_q"]
+    for b, sy in enumerate(systems):
+        if len(sy.pieces) != n - 1:
+            return None
+        seen = {}
+        for i, (Q, dt, _) in enumerate(sy.pieces):
+            k = seen.get(id(Q))
+            if k is None:                                      # first appearance: copy the matrix
+                k = seen[id(Q)] = len(seen)
+                if k >= len(q_size) or Q.shape[0] != q_size[k]:
+                    return None                                # another piece pattern: numpy path
+                Qs[b, q_pos[k]:q_pos[k + 1]] = np.asarray(Q, dtype=np.float64).ravel()
+            if k != piece_q[i]:
+                return None
+            dts[b, i] = dt
+        starts[b] = sy.start
+    pi = np.empty((nb, n))
+    T = np.empty((nb, n, n))
+    threads = min(16, os.cpu_count() or 1) if nb >= 8 else 1
+    call = _native.get("call")
+    if call is None:            # raw addresses instead of typed pointer objects: 15 data_as() calls cost more than the recursion
+        vp = ctypes.c_void_p
+        proto = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp, ctypes.c_int, vp, vp,
+                                 vp, vp, vp, vp, vp, ctypes.c_int)
+        call = _native["call"] = proto(("imc_model_transitions", lib))
+    addr = st.get("addr")
+    if addr is None:
+        addr = st["addr"] = tuple(st[k].ctypes.data for k in ("space_size", "cls_off", "cls_idx", "piece_q", "piece_proj", "proj_off", "proj"))
+    rc = call(nb, n, addr[0], addr[1], addr[2], addr[3], addr[4], st["n_q"], q_size.ctypes.data, len(st["proj_off"]), addr[5], addr[6],
+              Qs.ctypes.data, dts.ctypes.data, starts.ctypes.data, pi.ctypes.data, T.ctypes.data, threads)
+    if rc != 0:
+        msg = lib.imc_last_error().decode("utf-8", "replace")
+        if "must be supported on the B class" in msg:
+            raise ValueError(msg)
+        raise AssertionError(msg)
+    return pi, T
+
+
 def hmm_transitions_batch(systems):
     """Initial distributions ``(B, n)`` and transition matrices ``(B, n, n)`` of B CoalHMMs that
     share one interval structure (transitions.py:204-248).
@@ -325,6 +460,9 @@ def hmm_transitions_batch(systems):
     paths never leave L) and closed with ``through_j[L, E] 1``.  All B systems advance together
     as stacked matrix products.
     """
+    done = _native_transitions(systems)
+    if done is not None:
+        return done
     spaces = systems[0].spaces
     n = len(spaces)
     nb = len(systems)

@@ -216,8 +216,9 @@ int imc_set_rank1_handoff(int on);
 int imc_set_blocked_kernel(int variant);
 /* Where k_zpropagate4 takes a step's operator from: -1 (default) = automatic - STREAMED from the global table (every
  * step's operands are requested one step ahead and arrive from L1 / L2 / the Infinity Cache; nothing is cached in LDS)
- * while the tables of one launch (all parameter sets) are at most 32 MB, the HYBRID form (hottest operators cached in
- * LDS, the others streamed) beyond that; 0 = always hybrid; 1 = always streamed (A/B measurements, tests).
+ * whenever a launch holds several parameter sets (XCD-affine grid, IMC_XCD_AFFINE) or one set's table of at most 32 MB
+ * (always, up to 24 states), the HYBRID form (hottest operators cached in LDS, the others streamed) otherwise;
+ * 0 = always hybrid; 1 = always streamed (A/B measurements, tests).
  * IMC_Z4_STREAM=-1|0|1 in the environment sets the mode at start-up. */
 int imc_set_table_streaming(int mode);
 /* Description of the last launch plan, out8[0..7] = segments, vectors, per-column segment length,

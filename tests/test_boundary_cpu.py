@@ -23,7 +23,7 @@ def lib():
 
 
 def test_header_symbols_all_exported(lib):
-    hdr = open(os.path.join(REPO, "include", "imcoal_fwd.h")).read()
+    hdr = "".join(open(os.path.join(REPO, "include", f)).read() for f in sorted(os.listdir(os.path.join(REPO, "include"))) if f.endswith(".h"))
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(imc_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 18

@@ -170,3 +170,84 @@ def test_build_speed_n150():
         m.build_hidden_markov_model(theta * (1 + 1e-3))
     per = (time.perf_counter() - t0) / 5
     assert per < 0.25, "N=150 HMM build took %.3f s (reference: ~1.6 s)" % per
+
+
+# ---------------------------------------------------------------------------------------------
+# native path (csrc/model_host.hpp, include/imcoal_model.h) against the numpy path
+# ---------------------------------------------------------------------------------------------
+
+class _numpy_only(object):
+    """Switch the native path off inside a with-block (the golden tests above run through it whenever the library is built)."""
+    def __enter__(self):
+        self.saved = dict(M._native)
+        M._native.update(lib=None, tried=True)
+
+    def __exit__(self, *exc):
+        M._native.update(self.saved)
+
+
+def _native_or_skip():
+    if M._native_lib() is None:
+        pytest.skip("libimcoal_fwd.so is not built: the numpy path is the only one")
+
+
+@pytest.mark.parametrize("make,theta", [
+    (lambda: M.IsolationModel(10), [0.001, 1000.0, 0.4]),
+    (lambda: M.IsolationModel(20), [0.002, 800.0, 0.6]),
+    (lambda: M.IsolationModel(2), [0.001, 1000.0, 0.4]),
+    (lambda: M.VariableCoalescenceRateIsolationModel([2, 3, 1]), None),
+    (lambda: M.VariableCoalescenceRateIsolationModel([1, 2, 2], est_split=True), None),
+])
+def test_native_and_numpy_paths_agree(make, theta):
+    _native_or_skip()
+    model = make()
+    if theta is None:
+        key = "vcr_split" if getattr(model, "est_split", False) else "vcr_nosplit"
+        theta = GOLD[key + "_theta"]
+    theta = np.asarray(theta, dtype=np.float64)
+    thetas = np.stack([theta * (1.0 + 0.03 * k) for k in range(9)])
+    pi_n, T_n, E_n = model.build_hidden_markov_model(theta)
+    pis_n, Ts_n, Es_n = model.build_batch(thetas)
+    assert M._native["structures"], "the native path did not run"
+    with _numpy_only():
+        pi_p, T_p, E_p = model.build_hidden_markov_model(theta)
+        pis_p, Ts_p, Es_p = model.build_batch(thetas)
+    assert np.abs(pi_n - pi_p).max() < 1e-13 and np.abs(T_n - T_p).max() < 1e-13 and (E_n == E_p).all()
+    assert np.abs(pis_n - pis_p).max() < 1e-13 and np.abs(Ts_n - Ts_p).max() < 1e-13 and (Es_n == Es_p).all()
+    assert np.abs(pis_n[0] - pi_n).max() < 1e-15 and np.abs(Ts_n[0] - T_n).max() < 1e-15     # a system's result does not depend on its batch
+
+
+def test_native_expm_matches_scipy():
+    _native_or_skip()
+    import scipy.linalg
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 4, 15, 31):
+        for scale in (1e-4, 1e-2, 0.2, 0.9, 2.0, 2.2, 4.5, 5.3, 6.0, 40.0, 900.0):     # every Pade degree and the scaled branch
+            Q = rng.random((n, n)) * scale / n
+            np.fill_diagonal(Q, 0.0)
+            np.fill_diagonal(Q, -Q.sum(axis=1))
+            got = M.expm(Q)
+            assert np.abs(got - scipy.linalg.expm(Q)).max() < 5e-13, (n, scale)
+            assert np.abs(got.sum(axis=1) - 1).max() < 1e-12
+
+
+def test_large_state_spaces_stay_on_numpy():
+    _native_or_skip()
+    before = len(M._native["structures"])
+    m = M.IsolationMigrationModel(3, 3)                       # 94-state migration space > NATIVE_MAX_SPACE
+    m.build_hidden_markov_model(np.array([0.001, 0.001, 1000.0, 0.4, 200.0]))
+    new = list(M._native["structures"].values())[before:]
+    assert all(st is False for st in new)
+
+
+def test_start_outside_the_begin_class_is_refused_on_both_paths():
+    sp = M.single_space()
+    Q = sp.rate_matrix(M.single_rates(1000.0, 0.4))
+    bad = np.zeros(sp.size)
+    bad[sp.end_states[0]] = 1.0
+    system = M.PiecewiseCTMC(bad, [sp] * 3, [(Q, 1e-3, None), (Q, 2e-3, None)])
+    with pytest.raises(ValueError):
+        M.hmm_transitions(system)
+    with _numpy_only():
+        with pytest.raises(ValueError):
+            M.hmm_transitions(system)
