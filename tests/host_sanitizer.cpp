@@ -1,11 +1,77 @@
 #include "../imcoalhmm_amd/csrc/pair_dict.hpp"
 #include "../imcoalhmm_amd/csrc/obs_io.hpp"
+#include "../imcoalhmm_amd/csrc/model_host.hpp"
 #include <random>
 #include <cstdio>
 // Trains dictionaries (byte phase and, on the long low-entropy streams, the 16-bit round phase), encodes every
 // level, decodes it back, and round-trips the packed cache format.  Built with -fsanitize=address,undefined.
+// Host-side model construction (model_host.hpp): expm over every Pade degree and the scaled branch, and the (pi, T)
+// recursion on random piecewise systems with changing state spaces, projections and repeated pieces.  The class structure
+// is random, so the joint matrix need not sum to one - the routine then returns its error text; what is checked here is
+// that nothing reads or writes out of bounds on the way.
+static int model_host_checks(std::mt19937 &rng)
+{
+    std::vector<double> work;
+    for (int n : {1, 2, 4, 15, 33}) {
+        for (double scale : {1e-4, 0.1, 0.5, 1.5, 3.0, 6.0, 50.0, 2000.0}) {
+            std::vector<double> Q((size_t)n * n), out((size_t)n * n);
+            for (int i = 0; i < n; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < n; ++j)
+                    if (j != i) { Q[(size_t)i * n + j] = (rng() % 1000) * 1e-3 * scale / n; s += Q[(size_t)i * n + j]; }
+                Q[(size_t)i * n + i] = -s;
+            }
+            if (!imc_model::expm(Q.data(), out.data(), n, work)) { std::printf("expm failed\n"); return 1; }
+            for (int i = 0; i < n; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < n; ++j) s += out[(size_t)i * n + j];
+                if (std::fabs(s - 1.0) > 1e-9) { std::printf("expm of a generator: row sum %.3e off (n %d scale %g)\n", s - 1.0, n, scale); return 1; }
+            }
+        }
+    }
+    for (int rep = 0; rep < 40; ++rep) {
+        const int n = 1 + rep % 9;
+        std::vector<int32_t> space_size(n), cls_off(1, 0), cls_idx, piece_q(std::max(0, n - 1)), piece_proj(std::max(0, n - 1), -1);
+        const int sa = 3 + rng() % 6, sb = 2 + rng() % 5;               // two state spaces; the switch happens once
+        const int sw = n > 1 ? (int)(rng() % n) : 0;
+        for (int i = 0; i < n; ++i) space_size[i] = i <= sw ? sa : sb;
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) {                               // random (possibly empty, possibly overlapping) classes
+                for (int z = 0; z < space_size[i]; ++z)
+                    if (rng() % 3 == (unsigned)k || (k == 0 && z == 0)) cls_idx.push_back(z);
+                cls_off.push_back((int32_t)cls_idx.size());
+            }
+        std::vector<int32_t> q_size = {sa, sb}, proj_off = {0};
+        std::vector<double> proj((size_t)sa * sb, 0.0);
+        for (int r = 0; r < sa; ++r) proj[(size_t)r * sb + rng() % sb] = 1.0;
+        for (int i = 0; i + 1 < n; ++i) {
+            piece_q[i] = space_size[i] == sa ? 0 : 1;
+            if (space_size[i] != space_size[i + 1]) piece_proj[i] = 0;
+        }
+        std::vector<double> Q((size_t)sa * sa + (size_t)sb * sb), dt(std::max(0, n - 1)), start(space_size[0], 0.0), pi(n), T((size_t)n * n);
+        for (int which = 0; which < 2; ++which) {
+            const int m = which ? sb : sa;
+            double *M = Q.data() + (which ? (size_t)sa * sa : 0);
+            for (int i = 0; i < m; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < m; ++j)
+                    if (j != i) { M[(size_t)i * m + j] = (rng() % 100) * 0.05; s += M[(size_t)i * m + j]; }
+                M[(size_t)i * m + i] = -s;
+            }
+        }
+        for (size_t i = 0; i < dt.size(); ++i) dt[i] = (rng() % 3 == 0 && i > 0) ? dt[i - 1] : (1 + rng() % 50) * 0.01;   // repeated pieces
+        start[cls_idx[0]] = 1.0;                                        // (state 0 is always in interval 0's B class)
+        std::vector<int32_t> q_off = {0, sa * sa};
+        imc_model::Structure st{n, space_size.data(), cls_off.data(), cls_idx.data(), piece_q.data(), piece_proj.data(), 2, q_size.data(),
+                                q_off.data(), sa * sa + sb * sb, proj_off.data(), proj.data()};
+        (void)imc_model::transitions_one(st, Q.data(), dt.data(), start.data(), pi.data(), T.data());     // (result or error text)
+    }
+    return 0;
+}
+
 int main() {
     std::mt19937 rng(1);
+    if (model_host_checks(rng)) return 1;
     int wide_levels = 0;
     for (int rep = 0; rep < 22; ++rep) {
         const int nsym = 2 + rep % 5;
