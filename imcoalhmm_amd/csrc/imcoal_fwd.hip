@@ -540,7 +540,7 @@ KernelChoice make_kc()
         k.zip3 = k_zpropagate3<NP / 4>;
         k.zip3_lds = &Zip3Geom<NP / 4>::lds_bytes;
         k.tok_doubles = Zip3Geom<NP / 4>::TOK;
-        if constexpr (NP <= 20) {   // (NP = 24: the extra 36 operand registers of the hybrid form would spill)
+        if constexpr (NP <= 24) {   // (NP = 24: 27-29 registers of the streamed form spill, 35-72 of the hybrid one)
             k.zip4 = k_zpropagate4<NP / 4, false, true>;
             k.zip4w = k_zpropagate4<NP / 4, true, true>;
             k.zip4s = k_zpropagate4<NP / 4, false, false>;
@@ -909,6 +909,9 @@ struct PlanBuilder {
                         const bool hybrid_ok = !fits && kc->zip4 && g.blocked_variant >= 4 && max_hot >= 8 && !o0->tok_count[l].empty() &&
                                                table_bytes <= 2.0e9;
                         if (!fits && !hybrid_ok) continue;
+                        // (the scan's LDS: the fold's exchange area + the exponents and slot map of all A + 1 entries - at 24
+                        // states the exchange area alone is 152 KB and levels beyond 768 tokens do not fit)
+                        if (!fits && kc->zip4_lds(A, 0) > LDS_BUDGET) continue;
                         int passes = 0;
                         {
                             std::map<int, int> per_depth;
@@ -999,7 +1002,7 @@ struct PlanBuilder {
                     const imc_obs *o0 = chunks[kv.second[0]];
                     const bool hybrid = mfma_blocked && kc->zip4 && g.blocked_variant >= 4 && !o0->wide_raw;
                     const int amax_forced = hybrid ? HYBRID_MAX_ALPHABET : a_max;
-                    if (l >= 0 && l < imc::kNumLevels && o0->alphabet[l] <= amax_forced && o0->alphabet[l] > o0->nsym && o0->d_tok[l] &&
+                    if (l >= 0 && l < imc::kNumLevels && o0->alphabet[l] <= amax_forced && !(hybrid && kc->blocked_lds(o0->alphabet[l]) > LDS_BUDGET && kc->zip4_lds(o0->alphabet[l], 0) > LDS_BUDGET) && o0->alphabet[l] > o0->nsym && o0->d_tok[l] &&
                         (hybrid ? !o0->tok_count[l].empty() : !o0->wide[l])) best_l = l;
                 }
                 dict_level[kv.first] = best_l;
