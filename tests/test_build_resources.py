@@ -28,6 +28,11 @@ def test_hot_kernels_do_not_spill():
             # the 16-wavefront vector token kernel (24 < N <= 64, few chunks x many proposals) has had 36-152 bytes
             # of prologue spill in four of its shapes since round 1 (128-register budget); everything else: none
             limit = 192 if "12k_zpropagateI" in name else 0
+            # 21-24 states: P, Q and one operand set are 3 x 72 registers of the 256 - the streamed form spills 27-29 VGPRs,
+            # the hybrid one (tests only) up to 72, and the launch is still 1.9-2.3x faster than the 32-token LDS table it
+            # replaced (profiles/r03_h_states24_levels.txt)
+            if "13k_zpropagate4ILi6E" in name:
+                limit = 320
             if int(m.group(1)) > limit:
                 bad.append((name, int(m.group(1))))
     assert seen >= 40, seen            # every shape of every family was looked at
