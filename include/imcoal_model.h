@@ -1,7 +1,7 @@
 /* imcoal_model.h - host-side helper of libimcoal_fwd.so for SURVEY.md section 8f rank 3 ("host-side (pi,T,E)
  * construction throughput").  NOT part of the forward boundary (include/imcoal_fwd.h is): no device is touched, the
  * call works on a machine without a GPU, and imcoalhmm_amd/models.py computes the same numbers with numpy when the
- * library is absent or the state spaces are large.
+ * library is absent or the state spaces are large (more than 32 states), or when IMC_MODEL_NATIVE=0 is set.
  *
  * Replaces, for one or many parameter points at once, /root/reference/src/IMCoalHMM/transitions.py:204-248
  * (CTMCSystem -> joint matrix J -> initial distribution pi and transition matrix T) including the matrix exponentials of
