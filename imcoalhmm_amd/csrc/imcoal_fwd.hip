@@ -1118,10 +1118,17 @@ struct PlanBuilder {
                     size_t seg_blk = 16;
                     double slots = 0.0, cost_blk = 1e300;
                     // a workgroup takes 32 consecutive segments of ONE chunk: rows are allocated per chunk in 32s
+                    // (... except chunks that are ONE segment: those are packed, a row each - make_units)
+                    const bool can_pack = kc->use3() && !op_mode;
                     auto rows_used = [&](size_t sg) {
-                        double r = 0.0;
-                        for (size_t L : lens) r += std::ceil(std::ceil((double)L / (double)sg) / Z2SLOTS) * Z2SLOTS;
-                        return r;
+                        double r = 0.0, singles = 0.0;
+                        for (size_t L : lens) {
+                            if (!L) continue;
+                            const double nseg = std::ceil((double)L / (double)sg);
+                            if (nseg <= 1.0 && can_pack) singles += 1.0;
+                            else r += std::ceil(nseg / Z2SLOTS) * Z2SLOTS;
+                        }
+                        return r + std::ceil(singles / Z2SLOTS) * Z2SLOTS;
                     };
                     // Candidates: fill the machine's rows `rounds` times - or, when chunks x parameter sets alone need more
                     // rounds than that (every chunk takes at least one workgroup of 32 rows per parameter set: 100 chunks x 64
@@ -1144,6 +1151,24 @@ struct PlanBuilder {
                     }
                     for (size_t u = 1; u <= 8; ++u)
                         cands.push_back(std::max<size_t>(16, round_up((lmax + Z2SLOTS * u - 1) / (Z2SLOTS * u), Z2GRAN)));
+                    // ... and, for mixes of one long chunk with many short ones, the same for the MEDIAN chunk plus a few fixed
+                    // short lengths: both families above follow the longest chunk, and when the short chunks alone need more
+                    // than 16 rounds (each takes a workgroup per parameter set whatever the segment length) every candidate
+                    // was hundreds of tokens long - 500 chunks of 1e5 columns beside one of 2.5e7, 8 sets, 20 states: 432-token
+                    // segments, two of a workgroup's 32 rows in use on 4000 workgroups, 5.7 ms against 2.5.
+                    {
+                        std::vector<size_t> sorted(lens);
+                        std::sort(sorted.begin(), sorted.end());
+                        const size_t med = sorted[sorted.size() / 2];
+                        for (size_t u = 1; u <= 4; ++u)
+                            cands.push_back(std::max<size_t>(16, round_up((med + Z2SLOTS * u - 1) / (Z2SLOTS * u), Z2GRAN)));
+                        for (size_t fixed_len : {16, 32, 48, 64, 96, 128, 192}) cands.push_back(fixed_len);
+                        // whole chunks as single segments (packed 32 to a workgroup): the length of the median, the 90 % and the
+                        // longest chunk
+                        if (can_pack)
+                            for (size_t qi : {sorted.size() / 2, sorted.size() * 9 / 10, sorted.size() - 1})
+                                cands.push_back(std::max<size_t>(16, round_up(sorted[qi], Z2GRAN)));
+                    }
                     for (size_t sg : cands) {
                         // per round of workgroups: the main loop, plus the table rebuild and the 5-level in-kernel fold
                         // (table: the VALU form builds token by token; the MFMA form one dictionary depth per pass,
@@ -1156,7 +1181,9 @@ struct PlanBuilder {
                         // ones 109.6) - so the next multiple of 16 is priced beside the exact fit.
                         for (size_t cand : {sg, round_up(sg, 16)}) {
                             const double u = rows_used(cand);
-                            const double c = std::ceil(u * B / rows) * ((double)cand * (Z2WAVES / 4.0) * step_cycles + fixed + (cand % 16 ? 7700.0 : 0.0));
+                            double c = std::ceil(u * B / rows) * ((double)cand * (Z2WAVES / 4.0) * step_cycles + fixed + (cand % 16 ? 7700.0 : 0.0));
+                            // (every chunk a single packed segment: measured 10 % behind the best split where the model has a tie)
+                            if (can_pack && cand >= lmax) c *= 1.15;
                             if (c < cost_blk) { cost_blk = c; seg_blk = cand; slots = u; }
                         }
                     }
@@ -1264,7 +1291,17 @@ struct PlanBuilder {
                     const int nv = fst ? 1 : N;
                     for (int c = 0; c < nv; ++c) vecs.push_back(VecDesc{sid, (uint32_t)c});
                     if (gr.big) { gr.seg_ids.push_back(sid); gr.seg_out.push_back(unit_vec0[uid]); }
-                    if (gr.zip2) gr.blocks.push_back(Z2Block{sid, ns, unit_vec0[uid], fst ? 1u : 0u});
+                    if (gr.zip2) {
+                        // A chunk that is ONE segment needs no fold: up to 32 consecutive such chunks share a workgroup, each
+                        // in a slot of its own (Z2Block::first == 2).  One workgroup per chunk left 31 of 32 rows idle when
+                        // the chunks are short (10000 chunks of 1e4 columns, 20 states: 39 rounds of workgroups, 1.97 ms).
+                        const bool whole = kc->use3() && fst && ns == 1 && chunk_units[f].size() == 1;
+                        if (whole && !gr.blocks.empty() && gr.blocks.back().first == 2 && gr.blocks.back().n < Z2SLOTS &&
+                            gr.blocks.back().seg0 + gr.blocks.back().n == sid && gr.blocks.back().out_vec0 + gr.blocks.back().n == unit_vec0[uid])
+                            ++gr.blocks.back().n;
+                        else
+                            gr.blocks.push_back(Z2Block{sid, ns, unit_vec0[uid], whole ? 2u : fst ? 1u : 0u});
+                    }
                     for (uint32_t q2 = 0; q2 < ns; ++q2)
                         gr.vsteps += (uint64_t)((seg_first[sid + q2] && !gr.zip2) ? 1 : N) * segs[sid + q2].len;
                 }
@@ -1285,7 +1322,10 @@ struct PlanBuilder {
                     for (size_t u = 0; u < chunk_units[f].size(); ++u)
                         gr.tails.push_back(Z2Tail{(uint32_t)f, (uint32_t)u, (uint32_t)chunk_units[f].size(), 0u});
                 gr.tail_stride = (int)most;
-                if (gr.tails.size() != gr.blocks.size()) gr.tails.clear();      // (cannot happen: one entry per workgroup)
+                if (gr.tails.size() != gr.blocks.size()) gr.tails.clear();      // packed blocks: several chunks share a workgroup
+                else
+                    for (Z2Block &bk : gr.blocks)                               // (a packed block of ONE chunk is an ordinary first block,
+                        if (bk.first == 2) bk.first = 1;                        //  and the fused tail writes that chunk's result)
             }
         }
         if (vecs.size() >= (size_t)UINT32_MAX / 2) return fail(IMC_ERR_ARG, "too many vectors in one call");

@@ -22,7 +22,8 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 struct Z2Block {                  // one workgroup of k_zpropagate2: up to Z2SLOTS consecutive segments of one chunk
     uint32_t seg0, n;             // first segment id, number of segments
     uint32_t out_vec0;            // where the block's combined result goes (level-0 vector index)
-    uint32_t first;               // 1: seg0 is its chunk's first segment -> the result is a vector
+    uint32_t first;               // 1: seg0 is its chunk's first segment -> the result is a vector; 2 (MFMA forms): a PACKED block -
+                                  // every one of the n segments is a whole chunk, slot s writes its vector to out_vec0 + s, no fold
 };
 
 struct Z2Tail { uint32_t chunk, unit, n_units, pad; };

@@ -440,6 +440,18 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate3(BigAr
         masked_block(bi, min(RESCALE_EVERY, (maxlen - bi * RESCALE_EVERY + 1) & ~1));
     zip3_rescale<NT>(P, ex);
 
+    // ---- packed block (Z2Block::first == 2): every slot is a whole one-segment chunk - its vector goes out as it is ----
+    if (blk.first == 2) {                                   // (workgroup-uniform: nobody reaches the fold's barriers)
+        if (slot < (int)blk.n && r == 0) {
+            const size_t gvp = (size_t)b * a.n_vecs_total + blk.out_vec0 + slot;
+#pragma unroll
+            for (int K = 0; K < NT; ++K)
+                if (4 * K + q < a.N) a.P[gvp * NP + 4 * K + q] = P[K][0];
+            if (q == 0) a.EX[gvp] = ex;
+        }
+        return;
+    }
+
     // ---- fold the workgroup's segments into one (zip3_fold): the operator table is dead once every wavefront is
     // here; its space becomes the exchange area ----
     zip3_fold<NT, true>(P, ex, C, cex, (int)blk.n, slot, tid >> 6, lo, lx);

@@ -703,6 +703,18 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024 && blockIdx.y == 0) g_z4_dbg[1024 * 8 + blockIdx.x * 8 + (threadIdx.x >> 6)] = wall_clock64();
 #endif
 
+    // ---- packed block (Z2Block::first == 2): every slot is a whole one-segment chunk - its vector goes out as it is ----
+    if (blk.first == 2) {                                   // (workgroup-uniform: nobody reaches the fold's barriers)
+        if (valid && r == 0) {
+            const size_t gvp = (size_t)b * a.n_vecs_total + blk.out_vec0 + slot;
+#pragma unroll
+            for (int K = 0; K < NT; ++K)
+                if (4 * K + q < a.N) a.P[gvp * NP + 4 * K + q] = P[K][0];
+            if (q == 0) a.EX[gvp] = ex;
+        }
+        return;
+    }
+
     // ---- fold the workgroup's segments into one (zip3_fold; the LDS entries become the exchange area; the streamed
     // form keeps nothing in LDS during the scan, so its wavefronts start folding as they finish) ----
     zip3_fold<NT, HYB>(P, ex, C, xex, (int)blk.n, slot, tid >> 6, lo, lx);

@@ -12,7 +12,7 @@ import pytest
 
 from conftest import rel_err
 from imcoalhmm_amd import Forwarder, Likelihood, _capi, synth
-from imcoalhmm_amd.hmm import forward_chunks, forward_chunks_batch
+from imcoalhmm_amd.hmm import forward_chunks, forward_chunks_batch, recompress
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-11
@@ -750,3 +750,37 @@ def test_every_number_of_parameter_sets_reaches_every_workgroup(oracle, hmm_para
         del fw
     finally:
         _capi.check(L.imc_set_compression(1)); _capi.check(L.imc_set_blocked_kernel(4)); _capi.check(L.imc_dictionary_reset())
+
+
+@pytest.mark.parametrize("n", [10, 20])
+def test_many_short_chunks_share_workgroups(oracle, hmm_params, n):
+    """Packed blocks (Z2Block::first == 2, csrc/imcoal_fwd.hip make_units): chunks that are a single segment take a slot each
+    of a shared workgroup instead of a workgroup each.  Hundreds of short chunks of every length around the 16-token block
+    size - runs of them broken by long chunks (which are cut and folded as before) and by empty ones - on the LDS-table and
+    the global-table kernel, two parameter sets: every chunk against the oracle."""
+    L = _capi.lib()
+    hm = [hmm_params("iso%d_t%d" % (n, b)) for b in range(2)]
+    pis, Ts, Es = (np.stack([h[k] for h in hm]) for k in range(3))
+    rng = np.random.default_rng(77 + n)
+    big = synth.sample_alignment(*hm[0], 900_000, seed=31 + n)
+    lens = [int(x) for x in rng.integers(1, 6000, size=230)]
+    for pos, m in ((0, 400_000), (57, 0), (58, 0), (120, 250_000), (121, 1), (229, 90_000)):
+        lens[pos] = m
+    offs = [int(rng.integers(0, big.size - m)) if m else 0 for m in lens]
+    chunks = [big[o:o + m] for o, m in zip(offs, lens)]
+    want = np.array([[oracle.forward_scaled(pis[b], Ts[b], Es[b], c) if c.size else 0.0 for c in chunks] for b in range(2)])
+    try:
+        for mode, variant, seg in ((1, 4, 0), (3, 3, 0), (3, 5, 0), (3, 5, 6000), (1, 4, 64)):
+            _capi.check(L.imc_set_compression(mode)); _capi.check(L.imc_set_blocked_kernel(variant)); _capi.check(L.imc_dictionary_reset())
+            fw = [Forwarder.from_array(c, 3) for c in chunks]
+            recompress([f for f in fw if len(f)])
+            _capi.check(L.imc_set_segment_length(seg))
+            for rep in range(2):
+                per = forward_chunks_batch([f.handle for f in fw], pis, Ts, Es, per_chunk=True)
+                bad = np.argwhere(np.abs(per - want) > TOL * np.abs(want))
+                assert bad.size == 0, (n, mode, variant, seg, rep, bad[:5], _capi.last_plan()["kernels"])
+            _capi.check(L.imc_set_segment_length(0))
+            del fw
+    finally:
+        _capi.check(L.imc_set_segment_length(0)); _capi.check(L.imc_set_compression(1)); _capi.check(L.imc_set_blocked_kernel(4))
+        _capi.check(L.imc_dictionary_reset())
