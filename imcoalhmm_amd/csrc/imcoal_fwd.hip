@@ -349,6 +349,14 @@ std::shared_ptr<DictDev> make_dictionary(const uint8_t *host, const imc::tok_t *
     } else {
         const size_t n = std::min(L - 1, DICT_TRAIN_MAX);
         imc::train_dict(nd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), 64, max_depth);
+        // The 16-bit rounds only start from a FULL byte dictionary.  On a large sample the byte phase can stop a few entries
+        // short (the best remaining pair under the depth cap has 63 occurrences) - and the chunk then has no level beyond
+        // ~250 tokens at all (seen once in a bench run: 96 instead of 150 columns per token, every evaluation 25-40 %
+        // slower).  Retrain with a lower threshold rather than lose the wide levels.
+        for (size_t min_count : {(size_t)8, (size_t)2}) {
+            if (nd->dict.alphabet >= imc::kByteAlphabet || nd->dict.alphabet < 3 * imc::kByteAlphabet / 4 || n < DICT_TRAIN_MIN) break;
+            imc::train_dict(nd->dict, nsym, std::vector<uint8_t>(host + 1, host + 1 + n), min_count, max_depth);
+        }
         if (nd->dict.alphabet >= imc::kByteAlphabet) {   // 16-bit tokens: rounds over the whole chunk's byte-level stream
             const size_t cols = std::min(L, DICT_WIDE_TRAIN_TOKENS * 96);   // a byte-level token covers ~60-100 columns
             const std::vector<uint8_t> lvl256 = imc::encode_bytes(nd->dict, host, cols, nullptr);
@@ -2390,7 +2398,10 @@ int imc_obs_recompress(imc_obs *const *chunks, int n_chunks)
     for (auto &kv : by_alphabet) {
         const int nsym = kv.first;
         std::vector<imc_obs *> &obs = kv.second;
-        std::sort(obs.begin(), obs.end());
+        // (in creation order, not in address order: the training sample is the concatenation of the chunks' heads, and with
+        // pointer order the dictionary - alphabet, token counts, now and then whether the byte phase filled its 256 entries
+        // at all - changed from run to run of the same program)
+        std::sort(obs.begin(), obs.end(), [](const imc_obs *x, const imc_obs *y) { return x->id < y->id; });
         obs.erase(std::unique(obs.begin(), obs.end()), obs.end());
         const bool wide_raw = nsym > imc::kByteAlphabet;
         const size_t unit = wide_raw ? sizeof(imc::tok_t) : 1;

@@ -74,3 +74,34 @@ def test_recompress_edge_cases(oracle, hmm_params):
         want = oracle.forward_scaled(*hmm300, skewed(k))
         assert rel_err(f.forward(*hmm300), want) < 1e-11
     _capi.check(L.imc_dictionary_reset())
+
+
+def test_joint_dictionary_does_not_depend_on_where_the_chunks_live(hmm_params):
+    """The training sample of imc_obs_recompress is the concatenation of the chunks' heads.  Until round 3 the chunks were
+    put in ADDRESS order first, so the dictionary - its size, the token counts, once even whether the byte phase filled its
+    256 entries and the 16-bit levels existed at all (a bench run came out 25-40 % slow) - changed from run to run of the same
+    program.  Same chunks, created twice with other allocations in between and handed over in another order: the same
+    dictionary, pair for pair, and the same values bit for bit."""
+    pi, T, E = hmm_params("iso10_t0")
+    L = _capi.lib()
+    chunks = [synth.sample_alignment(pi, T, E, 150_000 + 7_000 * k, seed=900 + k) for k in range(24)]
+    results = []
+    junk = []
+    for attempt in range(3):
+        _capi.check(L.imc_dictionary_reset())
+        junk.append([Forwarder.from_array(chunks[k][:5000 + 999 * attempt], 3) for k in range(attempt * 3)])   # shifts the heap
+        fw = [Forwarder.from_array(c, 3) for c in chunks]
+        order = list(range(len(fw)))
+        if attempt == 1:
+            order = order[::-1]
+        elif attempt == 2:
+            order = order[5:] + order[:5]
+        recompress([fw[k] for k in order])
+        s2p = fw[0].sym2pair                                           # {token: (left, right)}
+        pairs = sorted((int(t), tuple(int(x) for x in s2p[t])) for t in s2p)
+        value = forward_chunks_batch([f.handle for f in fw], pi[None], T[None], E[None], per_chunk=True)[0]
+        results.append((fw[0].new_nsyms, pairs, [f.compressed_length(1 << 30) for f in fw], value))
+        del fw
+    for other in results[1:]:
+        assert other[0] == results[0][0] and other[1] == results[0][1] and other[2] == results[0][2]
+        assert np.array_equal(other[3], results[0][3])
