@@ -44,11 +44,29 @@ def _batch_params(pis, Ts, Es):
     return pis, Ts, Es
 
 
+class HandleArray(object):
+    """The ``imc_obs*`` array of a fixed set of chunks, built once: with hundreds of files the list comprehension and the
+    ctypes array per evaluation cost as much as a small device pass (``Likelihood`` keeps one)."""
+
+    def __init__(self, handles):
+        handles = list(handles)
+        self.count = len(handles)
+        self.array = _capi.handle_array(handles)
+
+
+def _handles(handles):
+    if isinstance(handles, HandleArray):
+        return handles.array, handles.count
+    if isinstance(handles, ctypes.Array):
+        return handles, len(handles)
+    return _capi.handle_array(handles), len(handles)
+
+
 def forward_chunks(handles, pi, T, E):
     """Sum of chunk log-likelihoods for one parameter set (likelihood.py:33)."""
     pi, T, E = _params(pi, T, E)
-    harr = handles if isinstance(handles, ctypes.Array) else _capi.handle_array(handles)
-    return _capi.forward1(harr, len(handles), pi, T, E)
+    harr, count = _handles(handles)
+    return _capi.forward1(harr, count, pi, T, E)
 
 
 def forward_chunks_batch(handles, pis, Ts, Es, per_chunk=False):
@@ -56,13 +74,14 @@ def forward_chunks_batch(handles, pis, Ts, Es, per_chunk=False):
     B, n = pis.shape
     S = Es.shape[2]
     L = _capi.lib()
+    harr, count = _handles(handles)
     if per_chunk:
-        out = np.zeros((B, len(handles)), dtype=np.float64)
-        _capi.check(L.imc_forward_batch_per_chunk(_capi.handle_array(handles), len(handles), B, n, S,
+        out = np.zeros((B, count), dtype=np.float64)
+        _capi.check(L.imc_forward_batch_per_chunk(harr, count, B, n, S,
                                                   _capi.dptr(pis), _capi.dptr(Ts), _capi.dptr(Es), _capi.dptr(out)))
     else:
         out = np.zeros(B, dtype=np.float64)
-        _capi.check(L.imc_forward_batch(_capi.handle_array(handles), len(handles), B, n, S,
+        _capi.check(L.imc_forward_batch(harr, count, B, n, S,
                                         _capi.dptr(pis), _capi.dptr(Ts), _capi.dptr(Es), _capi.dptr(out)))
     return out
 

@@ -44,15 +44,26 @@ class Likelihood(object):
         ours = [f for f in self.forwarders if isinstance(f, hmm.Forwarder)]
         return ours, len(ours) == len(self.forwarders)
 
+    def _handle_array(self):
+        """The chunk handles as one array, built at the first evaluation (rebuilt if the list of forwarders is replaced or
+        changes length; its members are not expected to change behind it): None if some forwarder is not ours."""
+        cached = getattr(self, "_harr", None)
+        if cached is not None and cached[0] is self.forwarders and cached[1] == len(self.forwarders):
+            return cached[2]
+        ours, all_ours = self._split()
+        harr = hmm.HandleArray(f.handle for f in ours) if all_ours else None
+        self._harr = (self.forwarders, len(self.forwarders), harr)
+        return harr
+
     def __call__(self, *parameters):
         """Log-likelihood at one parameter point; -inf for invalid parameters (likelihood.py:29-30)."""
         if not self.model.valid_parameters(*parameters):
             return -float('inf')
         init_probs, trans_probs, emission_probs = self.model.build_hidden_markov_model(*parameters)
-        ours, all_ours = self._split()
-        if all_ours:
+        harr = self._handle_array()
+        if harr is not None:
             # chunk values are summed left to right from 0.0 inside the library, like Python's sum()
-            return hmm.forward_chunks([f.handle for f in ours], init_probs, trans_probs, emission_probs)
+            return hmm.forward_chunks(harr, init_probs, trans_probs, emission_probs)
         return sum(forwarder.forward(init_probs, trans_probs, emission_probs) for forwarder in self.forwarders)
 
     def batch(self, thetas):
@@ -66,9 +77,9 @@ class Likelihood(object):
         if not valid:
             return out
         pis, Ts, Es = build_hmms(self.model, [thetas[k] for k in valid])
-        ours, all_ours = self._split()
-        if all_ours:
-            vals = hmm.forward_chunks_batch([f.handle for f in ours], pis, Ts, Es)
+        harr = self._handle_array()
+        if harr is not None:
+            vals = hmm.forward_chunks_batch(harr, pis, Ts, Es)
         else:
             vals = [sum(f.forward(pis[b], Ts[b], Es[b]) for f in self.forwarders) for b in range(len(valid))]
         for k, v in zip(valid, vals):
