@@ -525,7 +525,11 @@ __global__ __launch_bounds__(Z2WAVES * 64, Z2WAVES / 4) void k_zpropagate4(BigAr
     const Z2Block blk = a.blocks[bx];
     const int slot = (tid >> 6) * 4 + bq;                   // 0..Z2SLOTS-1 within the workgroup
     const bool valid = slot < (int)blk.n;
-    const uint32_t seg = blk.seg0 + (valid ? slot : 0);
+    // A lane without a segment runs the wavefront's unconditional token loads on another segment's stream: the FIRST
+    // slot of its own wavefront (whose length bounds the wavefront's full blocks: nfull is a minimum over the valid
+    // lanes), not the workgroup's segment 0 - in a packed block (Z2Block::first == 2) that may be a one-column chunk
+    // beside a thousand-column one, and the loads then ran hundreds of bytes past its buffer (found under IMC_GUARD=1).
+    const uint32_t seg = blk.seg0 + (valid ? slot : ((slot & ~3) < (int)blk.n ? (slot & ~3) : 0));
     const SegDesc sd = a.segs[seg];
     const int len = valid ? (int)sd.len : 0;
     const bool first = (sd.first & SEG_FIRST) != 0;

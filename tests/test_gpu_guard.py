@@ -80,6 +80,14 @@ SCRIPT = textwrap.dedent('''
     check(70, [1, 16, 300, 60000, 36000], (0, 1, 2, 3), B=1)
     check(150, [90, 130_000], (1, 3), B=1)
     check(150, [40_000, 9_000], (5,), seg=4096, B=1)                   # GEMM chain + rank-one hand-off rounds
+    # Packed blocks (one-segment chunks sharing a workgroup, round 3) with VERY unequal lengths in one workgroup: a lane
+    # without a segment used to run its wavefront's unconditional token loads on the workgroup's segment 0 - here a
+    # one-column chunk beside a thousand-column one - hundreds of bytes past that chunk's buffer (found by running the
+    # parity suite under IMC_GUARD=1; DESIGN 8a(h)).
+    unequal = [1, 2, 15, 16, 17, 31, 32, 33, 1000, 3, 2500, 1, 1, 700]
+    check(20, unequal, (0, 1, 3, 5), seg=4096)
+    check(10, unequal, (0, 3), seg=1024)
+    check(20, unequal + [70001], (1, 3), seg=0)
     # The blocked MFMA kernels on a stream with NO merged tokens (mode 5: raw symbols, three table entries and the
     # identity; the launch carries no merge lists: tab_order / tab_lvl are null, tab_nlvl == 0).  Round 2's
     # gpurun_out/r2/pytest_i.log is this shape: an uncommitted build whose table prologue copied tab_lvl[0 .. tab_nlvl]
