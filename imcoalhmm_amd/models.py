@@ -185,9 +185,12 @@ class StateSpace(object):
     def rate_matrix(self, rates):
         """Generator matrix for a ``{label: rate}`` table (CTMC.py:12-37)."""
         per_label = np.array([float(rates[label]) for label in self.labels])
-        Q = np.zeros((self.size, self.size))
-        np.add.at(Q, (self._src, self._dst), per_label[self._label_of_edge])
-        Q[np.arange(self.size), np.arange(self.size)] = -Q.sum(axis=1)
+        flat = getattr(self, "_flat_edges", None)
+        if flat is None:
+            flat = self._flat_edges = self._src * self.size + self._dst
+        # (bincount adds the weights of equal (src, dst) pairs in edge order, as np.add.at did - at a third of the time)
+        Q = np.bincount(flat, weights=per_label[self._label_of_edge], minlength=self.size * self.size).reshape(self.size, self.size)
+        Q.ravel()[::self.size + 1] = -Q.sum(axis=1)
         return Q
 
     def projection_to(self, other, merge_populations):
@@ -345,8 +348,10 @@ def expm(A):
         return _scipy_expm(A)
     A = np.ascontiguousarray(A)
     out = np.empty_like(A)
-    dp = ctypes.POINTER(ctypes.c_double)
-    if lib.imc_model_expm(A.shape[0], A.ctypes.data_as(dp), out.ctypes.data_as(dp)) != 0:
+    call = _native.get("expm_call")
+    if call is None:
+        call = _native["expm_call"] = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)(("imc_model_expm", lib))
+    if call(A.shape[0], A.ctypes.data, out.ctypes.data) != 0:
         return _scipy_expm(A)
     return out
 
