@@ -926,7 +926,11 @@ struct PlanBuilder {
                             for (int z = o0->nsym; z < A; ++z) per_depth[kv.first->depth[z]]++;
                             for (auto &pd : per_depth) passes += (pd.second + (int)Z2SLOTS - 1) / (int)Z2SLOTS;
                         }
-                        const double nt = kc->NP / 4.0, t_step = std::max(0.25, 1.88 * nt * nt * nt / 125.0);
+                        // (up to 8 states a step is not MFMA time: measured round 3, 4 and 8 states, 64 sets - 0.08 / 0.14 us from
+                        // the LDS table, 0.19 / 0.22 from the global one; from 12 states on both follow the instruction count)
+                        const double nt = kc->NP / 4.0;
+                        const double t_step = nt < 1.5 ? 0.08 : nt < 2.5 ? 0.14 : std::max(0.25, 1.88 * nt * nt * nt / 125.0);
+                        const double t_step_g = nt < 1.5 ? 0.19 : nt < 2.5 ? 0.22 : t_step;
                         // Time of the scan itself: workgroups of 32 segments are dealt PER CHUNK (a chunk of u workgroups is cut
                         // into 32 u segments), and a launch of more workgroups than CUs runs in rounds, each paying the
                         // workgroup's fixed part again.  rounds x (fixed + segment length x step) for the best number of rounds -
@@ -975,7 +979,7 @@ struct PlanBuilder {
                             // ... which is latency; B tables of A operators are also two reads and a write of an operator per
                             // token and parameter set, at ~2.8 TB/s (measured round 3, 64 sets: 4096- against 512-token tables)
                             t_table += std::max(0.0, table_bytes * 3.0 / 2.8e6 - 0.5 * t_table);
-                            cost = t_table + scan_time(8.0, t_step * (streamed ? 1.06 : 1.0 + cold_pen * cold));
+                            cost = t_table + scan_time(8.0, t_step_g * (streamed ? 1.06 : 1.0 + cold_pen * cold));
                         }
                         if (g.blocked_variant == 5 && !fits) cost *= 1e-3;      // tests: the hybrid table wherever it is possible
                         if (std::getenv("IMC_DEBUG_LEVELS"))
