@@ -92,15 +92,18 @@ __device__ __forceinline__ void zip3_step(const double (&Pin)[NT][NT], double (&
 template <int NT>
 __device__ __forceinline__ void zip3_rescale(double (&P)[NT][NT], int &ex)
 {
-    double mx = 0.0;
+    // The exponent of the lane's largest entry from the HIGH words alone (entries are non-negative - or NaN, whose exponent
+    // field is the largest of all - so the sign-stripped high 32 bits order them as the values do): NT^2 32-bit maxima instead
+    // of NT^2 fp64 compare / compare-unordered / select triples.  The fp64 VALU shares the DP units with the matrix
+    // instruction, so those triples came straight out of the MFMA pipe's time, every 16 steps.
+    // (A largest entry below 2^-1022 counts as zero - the lane abstains - where frexp would have normalised it.)
+    int hmax = 0;
 #pragma unroll
     for (int K = 0; K < NT; ++K)
 #pragma unroll
-        for (int J = 0; J < NT; ++J) mx = (P[K][J] > mx || P[K][J] != P[K][J]) ? P[K][J] : mx;
-    int e = 0;
-    (void)frexp(mx, &e);
-    const bool zero = mx == 0.0;                       // an all-zero lane (padding rows, first-segment columns) abstains
-    e = zero ? INT_MIN : (mx > 0.0 && mx < INFINITY) ? e : INT_MAX;
+        for (int J = 0; J < NT; ++J) hmax = max(hmax, __double2hiint(P[K][J]) & 0x7fffffff);
+    const int field = hmax >> 20;
+    int e = field == 0 ? INT_MIN : field == 0x7ff ? INT_MAX : field - 1022;   // all-zero lane abstains; inf / NaN: leave alone
 #pragma unroll
     for (int m = 1; m <= 32; m = (m == 2 ? 16 : m * 2)) e = max(e, __shfl_xor(e, m, 64));
     e = (e == INT_MAX || e == INT_MIN) ? 0 : e;
